@@ -1,0 +1,127 @@
+/*
+ * rt_hip.h — C ABI of the MI355X (gfx950) wavefront path tracer, librt_hip.{so,a}.
+ *
+ * Drop-in boundary for ONE path of Davvos11/raytracer: what `run()` does between
+ * `world.init()` (src/main.rs:128) and the end of `cam.render(&world, &mut file, &mut data)`
+ * (src/main.rs:132, src/camera.rs:53-82).  The reference has no FFI; each entry point below
+ * names the reference interface it replaces.  All structs are POD with fixed-width fields,
+ * all pointers are plain host pointers unless a name starts with `d_`, all calls return
+ * 0 on success or a negative RT_E_* code (no exceptions or panics cross the ABI) and
+ * rt_last_error() describes the last failure on the calling thread.
+ *
+ * Threading: one host thread per process, one GPU per process (the device current when
+ * rt_init() ran).  Calls are blocking unless stated.  The library owns every device
+ * allocation it makes; host arrays are borrowed for the duration of the call.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RT_OK = 0, RT_E_ARG = -1, RT_E_HIP = -2, RT_E_STATE = -3, RT_E_LIMIT = -4 };
+
+/* trait Hittable implementors (src/hittable/sphere.rs:13-17, src/hittable/triangle.rs:12-18) */
+enum { RT_SPHERE = 0, RT_TRIANGLE = 1 };
+/* trait Material implementors (src/value/material.rs:23-25, 54-57, 82-84) */
+enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
+/* IntersectionAlgorithm (src/utils/rtweekend.rs:57-62) */
+enum { RT_ALGO_NAIVE = 0, RT_ALGO_BVH = 1, RT_ALGO_GRID = 2 };
+
+/* One Hittable.  sphere: v[0..2] = center, v[3] = radius.  triangle: v[0..2]=v0, v[3..5]=v1, v[6..8]=v2.
+ * `material` indexes the rt_material array. */
+typedef struct { uint32_t type; uint32_t material; double v[9]; } rt_prim;
+
+/* One Material.  Lambertian: albedo.  Metal: albedo, param = fuzz.  Dielectric: param = refraction_index. */
+typedef struct { uint32_t type; uint32_t pad; double albedo[3]; double param; } rt_material;
+
+/* BvhNode, field for field (src/acceleration/bvh.rs:35-42); `left`/`right` index the node array,
+ * `first`/`count` index the permuted object order handed to rt_scene_set_bvh(). */
+typedef struct { double min[3]; double max[3]; uint32_t is_leaf, left, right, first, count, pad; } rt_bvh_node;
+
+/* Grid (src/acceleration/grid.rs:11-18) minus the object and box vectors, which travel as flat tables. */
+typedef struct {
+    double box_size[3]; double origin[3]; double end[3]; double total_size[3];
+    uint64_t n_cells;
+} rt_grid_desc;
+
+/* Outputs of Camera::initialise (src/camera.rs:88-128) that get_ray (src/camera.rs:132-148) reads;
+ * the device does no trigonometry. */
+typedef struct {
+    uint32_t image_width, image_height;
+    double center[3], pixel00[3], du[3], dv[3], ddu[3], ddv[3];
+    double defocus_angle;
+} rt_camera;
+
+/* Data counters (src/value/data.rs:10-15), the split of intersection_checks by call site
+ * (box: bvh.rs:183, grid.rs:172 — primitive: hittable_list.rs:72, bvh.rs:197, grid.rs:287), and
+ * per-kernel device time measured with HIP events when rt_set_profiling(1) is on. */
+typedef struct {
+    uint64_t primary_rays, scatter_rays, intersection_checks, traversal_steps,
+             overlapping_aabb, gridbox_intersection_checks;
+    uint64_t box_tests, prim_tests;
+    uint64_t ray_segments;        /* rays pushed through extend = primary + continued scatter rays */
+    uint64_t extend_launches;
+    double   extend_ms;           /* sum of event-timed extend launches (0 when profiling is off) */
+    double   shade_ms, generate_ms, resolve_ms;
+    double   render_ms;           /* host wall time of the call, device synchronised on both sides */
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+/* Bind this process to `device` (hipSetDevice) and create the library's streams.  No reference
+ * counterpart (the reference is CPU only).  Must be called once before anything else. */
+int rt_init(int device);
+
+/* Per-launch HIP-event timing of the kernels on/off (default off). */
+int rt_set_profiling(int on);
+
+/* Replaces building `HittableList.objects` (src/hittable/hittable_list.rs:15-16): uploads the
+ * primitives (file order) and materials.  Returns NULL on failure. */
+rt_scene* rt_scene_create(const rt_prim* prims, uint32_t n_prims, const rt_material* mats, uint32_t n_mats);
+
+/* Replaces storing the result of Bvh::new in HittableList.bvh (hittable_list.rs:37): takes the
+ * host-built tree in the reference's own node layout and object permutation (`prim_index[k]` is
+ * the file-order index of the k-th object of Bvh.objects) and flattens it for the device. */
+int rt_scene_set_bvh(rt_scene*, const rt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* prim_index, uint32_t n_prims);
+
+/* Replaces HittableList.grid = Grid::new(...) (hittable_list.rs:43): per-cell AABB (min xyz, max xyz),
+ * CSR offsets (n_cells + 1) and the concatenated GridBox.objects lists (file-order indices). */
+int rt_scene_set_grid(rt_scene*, const rt_grid_desc*, const double* cell_aabb, const uint64_t* cell_offset, const uint32_t* prim_list);
+
+/* Parity entry: one `HittableList::hit(r, Interval(tmin,tmax), &mut HitRecord::default(), data)`
+ * (hittable_list.rs:65-102) per ray.  orig/dir are n*3 doubles (xyz interleaved).  Any output may be NULL.
+ * out_prim: file-order index of the last accepted primitive (-1: none); out_t: rec.t after the call;
+ * out_tp: the t at which rec.p was last written (rec.p == orig + out_tp*dir); out_hit: the return value. */
+int rt_trace(rt_scene*, int algorithm, const double* orig, const double* dir, uint64_t n, double tmin, double tmax,
+             int32_t* out_prim, double* out_t, double* out_tp, uint8_t* out_hit, rt_stats* stats);
+
+/* Parity entry for Camera::get_ray (camera.rs:132-148): primary ray of pixel (pix_i[k], pix_j[k]) for
+ * global sample index `sample`, with the library's counter RNG. */
+int rt_generate(const rt_camera*, uint64_t seed, uint32_t sample, const uint32_t* pix_i, const uint32_t* pix_j,
+                uint64_t n, double* orig, double* dir);
+
+/* Replaces the loops of Camera::render (camera.rs:64-73) for samples [s_begin, s_begin+s_count) of every
+ * pixel: out_sum[(j*W+i)*3+c] receives the sum of ray_color (camera.rs:153-186) over those samples, added
+ * in sample order.  `seed` keys the counter RNG; results do not depend on how samples are split over calls
+ * or GPUs (up to f64 summation order of the partial sums).  out_sum is a host buffer of W*H*3 doubles. */
+int rt_render(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+              uint64_t seed, double* out_sum, rt_stats* stats);
+
+/* Same, but the framebuffer stays in HBM: d_out_sum is a device buffer of W*H*3 doubles that is
+ * overwritten, and the call is ordered after prior work on `stream` (a hipStream_t, may be NULL) and
+ * complete on return.  This is what an spp-split multi-GPU host reduces with RCCL. */
+int rt_render_device(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                     uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats);
+
+/* Replaces dropping the HittableList. */
+void rt_scene_destroy(rt_scene*);
+
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

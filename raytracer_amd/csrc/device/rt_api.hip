@@ -1,0 +1,453 @@
+// rt_api.hip — extern "C" entry points of librt_hip (include/rt_hip.h): scene upload, BVH / grid
+// flattening, the wavefront bounce loop, and the parity entries.  Single translation unit with the kernels.
+#include "rt_kernels.hip"
+#include "../../../include/rt_hip.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(RT_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+bool g_inited = false;
+int g_device = -1;
+bool g_profiling = false;
+hipStream_t g_stream = nullptr;
+uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
+uint32_t g_stream_blocks = 2048;
+uint64_t g_batch_paths = 1ull << 24;  // paths in flight per batch
+
+struct EventPool {
+    std::vector<hipEvent_t> ev; size_t used = 0;
+    hipEvent_t get() {
+        if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+};
+EventPool g_events;
+struct TimedSpan { hipEvent_t a, b; int kind; };
+enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_RESOLVE };
+
+struct Workspace {
+    uint64_t cap = 0;            // path capacity
+    uint32_t depth_cap = 0;      // entries in `counts`
+    double* qbuf[2] = {nullptr, nullptr};   // 9 doubles per path each
+    uint32_t* qid[2] = {nullptr, nullptr};
+    int32_t* hit_prim = nullptr; double* hit_tp = nullptr;
+    double* rad = nullptr;
+    uint32_t* counts = nullptr;
+    unsigned long long* stats = nullptr;
+    uint32_t* h_count = nullptr; // pinned
+    unsigned long long* h_stats = nullptr;
+    void release() {
+        for (int i = 0; i < 2; ++i) { if (qbuf[i]) (void)hipFree(qbuf[i]); if (qid[i]) (void)hipFree(qid[i]); qbuf[i] = nullptr; qid[i] = nullptr; }
+        if (hit_prim) (void)hipFree(hit_prim); if (hit_tp) (void)hipFree(hit_tp); if (rad) (void)hipFree(rad);
+        if (counts) (void)hipFree(counts); if (stats) (void)hipFree(stats);
+        if (h_count) (void)hipHostFree(h_count); if (h_stats) (void)hipHostFree(h_stats);
+        hit_prim = nullptr; hit_tp = nullptr; rad = nullptr; counts = nullptr; stats = nullptr; h_count = nullptr; h_stats = nullptr;
+        cap = 0; depth_cap = 0;
+    }
+    RayQ q(int i) const {
+        RayQ r; double* b = qbuf[i];
+        r.ox = b; r.oy = b + cap; r.oz = b + 2 * cap; r.dx = b + 3 * cap; r.dy = b + 4 * cap; r.dz = b + 5 * cap;
+        r.tr = b + 6 * cap; r.tg = b + 7 * cap; r.tb = b + 8 * cap; r.id = qid[i];
+        return r;
+    }
+};
+
+V3 tov(const double* p) { V3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
+
+} // namespace
+
+struct rt_scene {
+    uint32_t n_prims = 0, n_mats = 0;
+    std::vector<rt_prim> h_prims;
+    DPrim* d_prims = nullptr;          // file order (naive, grid)
+    DMat* d_mats = nullptr;
+    // BVH
+    bool have_bvh = false; uint32_t n_nodes = 0, bvh_depth = 0;
+    DNode* d_nodes = nullptr; DPrim* d_prims_bvh = nullptr; StackEntry* d_stack = nullptr;
+    // grid
+    bool have_grid = false; DGrid grid{};
+    double* d_cell_aabb = nullptr; uint64_t* d_cell_offset = nullptr; uint32_t* d_prim_list = nullptr;
+    Workspace ws;
+};
+
+namespace {
+
+DPrim to_dprim(const rt_prim& p, uint32_t orig) {
+    DPrim d; for (int i = 0; i < 9; ++i) d.v[i] = p.v[i];
+    d.tm = (p.type == RT_TRIANGLE ? 0x80000000u : 0u) | (p.material & 0x7fffffffu);
+    d.orig = orig;
+    return d;
+}
+
+int ensure_workspace(rt_scene* sc, uint64_t cap, uint32_t depth_cap) {
+    Workspace& w = sc->ws;
+    if (w.cap >= cap && w.depth_cap >= depth_cap) return RT_OK;
+    if (cap < w.cap) cap = w.cap;
+    if (depth_cap < w.depth_cap) depth_cap = w.depth_cap;
+    w.release();
+    for (int i = 0; i < 2; ++i) {
+        HIPCHECK(hipMalloc(&w.qbuf[i], cap * 9 * sizeof(double)));
+        HIPCHECK(hipMalloc(&w.qid[i], cap * sizeof(uint32_t)));
+    }
+    HIPCHECK(hipMalloc(&w.hit_prim, cap * sizeof(int32_t)));
+    HIPCHECK(hipMalloc(&w.hit_tp, cap * sizeof(double)));
+    HIPCHECK(hipMalloc(&w.rad, cap * 3 * sizeof(double)));
+    HIPCHECK(hipMalloc(&w.counts, (size_t)depth_cap * sizeof(uint32_t)));
+    HIPCHECK(hipMalloc(&w.stats, ST_N * sizeof(unsigned long long)));
+    HIPCHECK(hipHostMalloc(&w.h_count, 64));
+    HIPCHECK(hipHostMalloc(&w.h_stats, ST_N * sizeof(unsigned long long)));
+    w.cap = cap; w.depth_cap = depth_cap;
+    return RT_OK;
+}
+
+int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* count, uint64_t n_fixed, double tmin, double tmax,
+                  const ExtendOut& out, hipStream_t st) {
+    dim3 grid(g_extend_blocks), block(RT_BLOCK);
+    switch (algorithm) {
+    case RT_ALGO_BVH:
+        if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
+        hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+        break;
+    case RT_ALGO_NAIVE:
+        hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->n_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+        break;
+    case RT_ALGO_GRID:
+        if (!sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called (reference: \"Please run Grid::new() first\")");
+        hipLaunchKernelGGL(k_extend_grid, grid, block, 0, st, sc->grid, sc->d_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+        break;
+    default:
+        return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
+    }
+    HIPCHECK(hipGetLastError());
+    return RT_OK;
+}
+
+const DPrim* shade_prims(const rt_scene* sc, int algorithm) { return algorithm == RT_ALGO_BVH ? sc->d_prims_bvh : sc->d_prims; }
+
+void fill_stats(rt_stats* s, const unsigned long long* h) {
+    s->scatter_rays = h[ST_SCATTER];
+    s->box_tests = h[ST_BOX]; s->prim_tests = h[ST_PRIM];
+    s->intersection_checks = h[ST_BOX] + h[ST_PRIM];
+    s->traversal_steps = h[ST_STEPS]; s->overlapping_aabb = h[ST_OVERLAP];
+    s->gridbox_intersection_checks = h[ST_GRIDBOX];
+    s->ray_segments = h[ST_SEGMENTS];
+}
+
+int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                uint64_t seed, double* d_fb, hipStream_t st, rt_stats* stats) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!sc || !cam || !d_fb) return fail(RT_E_ARG, "null argument");
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    if (WH == 0 || WH > 0x7fffffffull) return fail(RT_E_LIMIT, "image of %llu pixels is outside (0, 2^31)", (unsigned long long)WH);
+    if (algorithm == RT_ALGO_BVH && !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
+    if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
+    if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
+
+    uint32_t k = (uint32_t)(g_batch_paths / WH); if (k < 1) k = 1; if (k > s_count && s_count) k = s_count;
+    if (WH * k > 0xffffffffull) return fail(RT_E_LIMIT, "batch too large");
+    int rc = ensure_workspace(sc, WH * k, max_depth + 2);
+    if (rc) return rc;
+    Workspace& w = sc->ws;
+
+    DCamera dc; dc.W = cam->image_width; dc.H = cam->image_height;
+    dc.center = tov(cam->center); dc.pixel00 = tov(cam->pixel00); dc.du = tov(cam->du); dc.dv = tov(cam->dv);
+    dc.ddu = tov(cam->ddu); dc.ddv = tov(cam->ddv); dc.defocus_angle = cam->defocus_angle;
+
+    HIPCHECK(hipStreamSynchronize(st));
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHECK(hipMemsetAsync(w.stats, 0, ST_N * sizeof(unsigned long long), st));
+    std::vector<TimedSpan> spans;
+    g_events.reset();
+    double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
+    auto begin_span = [&](int kind) { if (g_profiling) { TimedSpan s; s.a = g_events.get(); s.b = g_events.get(); s.kind = kind; (void)hipEventRecord(s.a, st); spans.push_back(s); } };
+    auto end_span = [&]() { if (g_profiling) (void)hipEventRecord(spans.back().b, st); };
+    auto drain_spans = [&]() {
+        for (const TimedSpan& s : spans) { float f = 0; if (hipEventElapsedTime(&f, s.a, s.b) == hipSuccess) ms[s.kind] += f; }
+        spans.clear(); g_events.reset();
+    };
+
+    const dim3 sgrid(g_stream_blocks), block(RT_BLOCK);
+    const DPrim* sprims = shade_prims(sc, algorithm);
+    bool first = true;
+    if (s_count == 0) HIPCHECK(hipMemsetAsync(d_fb, 0, WH * 3 * sizeof(double), st));
+    for (uint32_t s0 = 0; s0 < s_count; s0 += k) {
+        const uint32_t kb = (s_count - s0 < k) ? (s_count - s0) : k;
+        HIPCHECK(hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * sizeof(uint32_t), st));
+        begin_span(K_GENERATE);
+        hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, s_begin + s0, kb, seed, w.q(0), w.counts);
+        end_span();
+        for (uint32_t b = 0; b < max_depth; ++b) {
+            ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.hit = nullptr; eo.trace = 0;
+            begin_span(K_EXTEND);
+            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, st);
+            if (rc) return rc;
+            end_span(); ++extend_launches;
+            begin_span(K_SHADE);
+            hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp,
+                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, b, max_depth, seed, w.stats);
+            end_span();
+            HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            if (g_profiling) drain_spans();
+            if (*w.h_count == 0) break;
+        }
+        begin_span(K_RESOLVE);
+        hipLaunchKernelGGL(k_accumulate, sgrid, block, 0, st, w.rad, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
+        end_span();
+        first = false;
+    }
+    HIPCHECK(hipMemcpyAsync(w.h_stats, w.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipGetLastError());
+    if (g_profiling) drain_spans();
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        fill_stats(stats, w.h_stats);
+        stats->primary_rays = WH * s_count;                           /* camera.rs:70, exact */
+        stats->extend_launches = extend_launches;
+        stats->generate_ms = ms[K_GENERATE]; stats->extend_ms = ms[K_EXTEND]; stats->shade_ms = ms[K_SHADE]; stats->resolve_ms = ms[K_RESOLVE];
+        stats->render_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(RT_E_HIP, "no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(RT_E_ARG, "device %d out of range [0,%d)", device, n);
+    HIPCHECK(hipSetDevice(device));
+    if (!g_inited || g_device != device) {
+        HIPCHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_device = device;
+    }
+    if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
+    if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
+    g_inited = true;
+    return RT_OK;
+}
+
+int rt_set_profiling(int on) { g_profiling = on != 0; return RT_OK; }
+
+rt_scene* rt_scene_create(const rt_prim* prims, uint32_t n_prims, const rt_material* mats, uint32_t n_mats) {
+    if (!g_inited) { fail(RT_E_STATE, "rt_init() has not been called"); return nullptr; }
+    if ((n_prims && !prims) || (n_mats && !mats)) { fail(RT_E_ARG, "null array"); return nullptr; }
+    if (n_prims > 0x3fffffffu) { fail(RT_E_LIMIT, "more than 2^30 primitives"); return nullptr; }
+    for (uint32_t i = 0; i < n_prims; ++i) {
+        if (prims[i].type > RT_TRIANGLE) { fail(RT_E_ARG, "primitive %u has unknown type %u", i, prims[i].type); return nullptr; }
+        if (prims[i].material >= n_mats) { fail(RT_E_ARG, "primitive %u names material %u of %u", i, prims[i].material, n_mats); return nullptr; }
+    }
+    for (uint32_t i = 0; i < n_mats; ++i)
+        if (mats[i].type > RT_DIELECTRIC) { fail(RT_E_ARG, "material %u has unknown type %u", i, mats[i].type); return nullptr; }
+    rt_scene* sc = new rt_scene();
+    sc->n_prims = n_prims; sc->n_mats = n_mats;
+    sc->h_prims.assign(prims, prims + n_prims);
+    std::vector<DPrim> dp(n_prims ? n_prims : 1);
+    for (uint32_t i = 0; i < n_prims; ++i) dp[i] = to_dprim(prims[i], i);
+    std::vector<DMat> dm(n_mats ? n_mats : 1);
+    for (uint32_t i = 0; i < n_mats; ++i) {
+        dm[i].albedo[0] = mats[i].albedo[0]; dm[i].albedo[1] = mats[i].albedo[1]; dm[i].albedo[2] = mats[i].albedo[2];
+        dm[i].param = mats[i].param; dm[i].type = mats[i].type; dm[i].pad = 0;
+    }
+    bool ok = hipMalloc(&sc->d_prims, dp.size() * sizeof(DPrim)) == hipSuccess
+           && hipMalloc(&sc->d_mats, dm.size() * sizeof(DMat)) == hipSuccess
+           && hipMemcpy(sc->d_prims, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice) == hipSuccess
+           && hipMemcpy(sc->d_mats, dm.data(), dm.size() * sizeof(DMat), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fail(RT_E_HIP, "scene upload failed: %s", hipGetErrorString(hipGetLastError())); rt_scene_destroy(sc); return nullptr; }
+    return sc;
+}
+
+void rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return;
+    (void)hipDeviceSynchronize();
+    if (sc->d_prims) (void)hipFree(sc->d_prims); if (sc->d_mats) (void)hipFree(sc->d_mats);
+    if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
+    if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
+    sc->ws.release();
+    delete sc;
+}
+
+int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* prim_index, uint32_t n) {
+    if (!sc || !nodes || (n && !prim_index)) return fail(RT_E_ARG, "null argument");
+    if (n != sc->n_prims) return fail(RT_E_ARG, "prim_index has %u entries, scene has %u primitives", n, sc->n_prims);
+    if (n_nodes == 0) return fail(RT_E_ARG, "empty node array");
+    // validate shape on the host: the kernel trusts indices, sibling adjacency and the depth bound
+    std::vector<uint8_t> seen(n_nodes, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> todo; todo.push_back({0u, 1u});
+    uint32_t depth = 0; uint64_t covered = 0;
+    while (!todo.empty()) {
+        auto [i, d] = todo.back(); todo.pop_back();
+        if (i >= n_nodes) return fail(RT_E_ARG, "node index %u out of range", i);
+        if (seen[i]) return fail(RT_E_ARG, "node %u reachable twice: not a tree", i);
+        seen[i] = 1; if (d > depth) depth = d;
+        const rt_bvh_node& nd = nodes[i];
+        if (nd.is_leaf) {
+            if ((uint64_t)nd.first + nd.count > n) return fail(RT_E_ARG, "leaf %u covers [%u,%u) of %u objects", i, nd.first, nd.first + nd.count, n);
+            covered += nd.count;
+        } else {
+            if (nd.right != nd.left + 1) return fail(RT_E_ARG, "node %u: children %u,%u are not adjacent (bvh.rs:167-168 makes them so)", i, nd.left, nd.right);
+            todo.push_back({nd.right, d + 1}); todo.push_back({nd.left, d + 1});
+        }
+    }
+    for (uint32_t k = 0; k < n; ++k) if (prim_index[k] >= n) return fail(RT_E_ARG, "prim_index[%u] = %u out of range", k, prim_index[k]);
+    std::vector<DNode> dn(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const rt_bvh_node& s = nodes[i]; DNode& d = dn[i];
+        for (int c = 0; c < 3; ++c) { d.mn[c] = s.min[c]; d.mx[c] = s.max[c]; }
+        if (s.is_leaf) { d.a = s.first; d.b = s.count | RT_LEAF; } else { d.a = s.left; d.b = 0; }
+        d.pad0 = d.pad1 = 0;
+    }
+    std::vector<DPrim> dp(n ? n : 1);
+    for (uint32_t k = 0; k < n; ++k) dp[k] = to_dprim(sc->h_prims[prim_index[k]], prim_index[k]);
+    if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
+    sc->d_nodes = nullptr; sc->d_prims_bvh = nullptr; sc->d_stack = nullptr; sc->have_bvh = false;
+    HIPCHECK(hipMalloc(&sc->d_nodes, dn.size() * sizeof(DNode)));
+    HIPCHECK(hipMalloc(&sc->d_prims_bvh, dp.size() * sizeof(DPrim)));
+    HIPCHECK(hipMalloc(&sc->d_stack, (size_t)depth * g_extend_blocks * RT_BLOCK * sizeof(StackEntry)));
+    HIPCHECK(hipMemcpy(sc->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(sc->d_prims_bvh, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    sc->n_nodes = n_nodes; sc->bvh_depth = depth; sc->have_bvh = true;
+    (void)covered;
+    return RT_OK;
+}
+
+int rt_scene_set_grid(rt_scene* sc, const rt_grid_desc* gd, const double* cell_aabb, const uint64_t* cell_offset, const uint32_t* prim_list) {
+    if (!sc || !gd || !cell_aabb || !cell_offset) return fail(RT_E_ARG, "null argument");
+    const uint64_t nc = gd->n_cells;
+    if (nc == 0) return fail(RT_E_ARG, "grid has no cells");
+    if (cell_offset[0] != 0) return fail(RT_E_ARG, "cell_offset[0] must be 0");
+    for (uint64_t i = 0; i < nc; ++i) if (cell_offset[i + 1] < cell_offset[i]) return fail(RT_E_ARG, "cell_offset not monotonic at %llu", (unsigned long long)i);
+    const uint64_t len = cell_offset[nc];
+    if (len && !prim_list) return fail(RT_E_ARG, "null prim_list");
+    for (uint64_t k = 0; k < len; ++k) if (prim_list[k] >= sc->n_prims) return fail(RT_E_ARG, "prim_list[%llu] out of range", (unsigned long long)k);
+    if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
+    sc->d_cell_aabb = nullptr; sc->d_cell_offset = nullptr; sc->d_prim_list = nullptr; sc->have_grid = false;
+    HIPCHECK(hipMalloc(&sc->d_cell_aabb, nc * 6 * sizeof(double)));
+    HIPCHECK(hipMalloc(&sc->d_cell_offset, (nc + 1) * sizeof(uint64_t)));
+    HIPCHECK(hipMalloc(&sc->d_prim_list, (len ? len : 1) * sizeof(uint32_t)));
+    HIPCHECK(hipMemcpy(sc->d_cell_aabb, cell_aabb, nc * 6 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(sc->d_cell_offset, cell_offset, (nc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (len) HIPCHECK(hipMemcpy(sc->d_prim_list, prim_list, len * sizeof(uint32_t), hipMemcpyHostToDevice));
+    DGrid& g = sc->grid;
+    g.box_size = tov(gd->box_size); g.origin = tov(gd->origin); g.end = tov(gd->end); g.total_size = tov(gd->total_size);
+    g.n_cells = nc;
+    double tz = gd->total_size[2];                                  /* grid.rs:152: `self.total_size.z() as u32` */
+    g.max_depth = !(tz > 0.0) ? 0u : (tz >= 4294967295.0 ? 0xffffffffu : (uint32_t)tz);
+    g.cell_aabb = sc->d_cell_aabb; g.cell_offset = sc->d_cell_offset; g.prim_list = sc->d_prim_list;
+    sc->have_grid = true;
+    return RT_OK;
+}
+
+int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir, uint64_t n, double tmin, double tmax,
+             int32_t* out_prim, double* out_t, double* out_tp, uint8_t* out_hit, rt_stats* stats) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!sc || (n && (!orig || !dir))) return fail(RT_E_ARG, "null argument");
+    if (algorithm == RT_ALGO_BVH && !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
+    if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
+    if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
+    const uint64_t chunk = 1ull << 22;
+    int rc = ensure_workspace(sc, n < chunk ? (n ? n : 1) : chunk, 4);
+    if (rc) return rc;
+    Workspace& w = sc->ws;
+    hipStream_t st = g_stream;
+    double *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; uint8_t* d_h = nullptr;
+    const uint64_t cmax = n < chunk ? (n ? n : 1) : chunk;
+    HIPCHECK(hipMalloc(&d_o, cmax * 3 * sizeof(double)));
+    HIPCHECK(hipMalloc(&d_d, cmax * 3 * sizeof(double)));
+    HIPCHECK(hipMalloc(&d_t, cmax * sizeof(double)));
+    HIPCHECK(hipMalloc(&d_h, cmax));
+    HIPCHECK(hipMemsetAsync(w.stats, 0, ST_N * sizeof(unsigned long long), st));
+    int ret = RT_OK;
+    for (uint64_t off = 0; off < n && ret == RT_OK; off += chunk) {
+        const uint64_t m = (n - off < chunk) ? (n - off) : chunk;
+        hipError_t e = hipMemcpyAsync(d_o, orig + 3 * off, m * 3 * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_d, dir + 3 * off, m * 3 * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { ret = fail(RT_E_HIP, "ray upload failed: %s", hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL(k_load_rays, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_o, d_d, m, w.q(0));
+        ExtendOut eo; eo.prim = w.hit_prim; eo.t = d_t; eo.tp = w.hit_tp; eo.hit = d_h; eo.trace = 1;
+        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, st);
+        if (ret) break;
+        if (out_prim) e = hipMemcpyAsync(out_prim + off, w.hit_prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && out_t) e = hipMemcpyAsync(out_t + off, d_t, m * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && out_tp) e = hipMemcpyAsync(out_tp + off, w.hit_tp, m * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && out_hit) e = hipMemcpyAsync(out_hit + off, d_h, m, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) ret = fail(RT_E_HIP, "trace failed: %s", hipGetErrorString(e));
+    }
+    if (ret == RT_OK) {
+        hipError_t e = hipMemcpy(w.h_stats, w.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) ret = fail(RT_E_HIP, "stats readback failed: %s", hipGetErrorString(e));
+        else if (stats) { memset(stats, 0, sizeof *stats); fill_stats(stats, w.h_stats); }
+    }
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_h);
+    return ret;
+}
+
+int rt_generate(const rt_camera* cam, uint64_t seed, uint32_t sample, const uint32_t* pix_i, const uint32_t* pix_j,
+                uint64_t n, double* orig, double* dir) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!cam || (n && (!pix_i || !pix_j || !orig || !dir))) return fail(RT_E_ARG, "null argument");
+    if (n == 0) return RT_OK;
+    for (uint64_t k = 0; k < n; ++k)
+        if (pix_i[k] >= cam->image_width || pix_j[k] >= cam->image_height) return fail(RT_E_ARG, "pixel %llu outside the image", (unsigned long long)k);
+    DCamera dc; dc.W = cam->image_width; dc.H = cam->image_height;
+    dc.center = tov(cam->center); dc.pixel00 = tov(cam->pixel00); dc.du = tov(cam->du); dc.dv = tov(cam->dv);
+    dc.ddu = tov(cam->ddu); dc.ddv = tov(cam->ddv); dc.defocus_angle = cam->defocus_angle;
+    uint32_t *d_i = nullptr, *d_j = nullptr; double *d_o = nullptr, *d_d = nullptr;
+    HIPCHECK(hipMalloc(&d_i, n * 4)); HIPCHECK(hipMalloc(&d_j, n * 4));
+    HIPCHECK(hipMalloc(&d_o, n * 24)); HIPCHECK(hipMalloc(&d_d, n * 24));
+    HIPCHECK(hipMemcpy(d_i, pix_i, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_j, pix_j, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_generate_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, dc, sample, seed, d_i, d_j, n, d_o, d_d);
+    HIPCHECK(hipStreamSynchronize(g_stream));
+    HIPCHECK(hipMemcpy(orig, d_o, n * 24, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(dir, d_d, n * 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d_i); (void)hipFree(d_j); (void)hipFree(d_o); (void)hipFree(d_d);
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                     uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats) {
+    return render_impl(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_out_sum, stream ? (hipStream_t)stream : g_stream, stats);
+}
+
+int rt_render(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+              uint64_t seed, double* out_sum, rt_stats* stats) {
+    if (!cam || !out_sum) return fail(RT_E_ARG, "null argument");
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    double* d_fb = nullptr;
+    HIPCHECK(hipMalloc(&d_fb, (WH ? WH : 1) * 3 * sizeof(double)));
+    int rc = render_impl(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_fb, g_stream, stats);
+    if (rc == RT_OK) {
+        hipError_t e = hipMemcpy(out_sum, d_fb, WH * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_E_HIP, "framebuffer readback failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_fb);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,181 @@
+// rt_device.h — device-side math, RNG, primitive tests and scatter functions (gfx950, f64).
+//
+// Every function cites the reference lines whose arithmetic it reproduces (paths under the reference
+// repo's src/).  The file must be compiled with -ffp-contract=off: the reference never fuses a
+// multiply-add, and hit/miss decisions are compared bit-for-bit against the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __device__ __forceinline__
+
+struct V3 { double x, y, z; };
+RT_DEV V3 v3(double a, double b, double c) { V3 r; r.x = a; r.y = b; r.z = c; return r; }
+RT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }            // value/vec3.rs:164-169
+RT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }            // :171-177
+RT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }                                 // :114-120
+RT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }            // :179-185
+RT_DEV V3 operator*(V3 a, double t) { return v3(a.x * t, a.y * t, a.z * t); }              // :187-193
+RT_DEV V3 operator*(double t, V3 a) { return a * t; }                                      // :195-201
+RT_DEV V3 operator/(V3 a, double t) { return (1.0 / t) * a; }                              // :203-209 (reciprocal, then multiply)
+RT_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                // :97-99
+RT_DEV double length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }           // :88-90
+RT_DEV V3 unit(V3 a) { return a / sqrt(length_squared(a)); }                               // :16-18, :84-86
+RT_DEV V3 cross(V3 a, V3 b) {                                                              // :101-107
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_DEV bool near_zero(V3 a) { const double s = 1e-8; return fabs(a.x) < s && fabs(a.y) < s && fabs(a.z) < s; } // :92-95
+RT_DEV V3 reflect(V3 v, V3 n) { return v - 2.0 * dot(v, n) * n; }                          // :53-55
+RT_DEV V3 refract(V3 uv, V3 n, double etai_over_etat) {                                    // :57-62
+    double cos_theta = fmin(dot(-uv, n), 1.0);
+    V3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    V3 r_out_parallel = -sqrt(fabs(1.0 - length_squared(r_out_perp))) * n;
+    return r_out_perp + r_out_parallel;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG replacing thread_rng() (utils/rtweekend.rs:166-169): Philox4x32-10,
+// key = seed, counter = (path_lo = pixel index j*W+i, path_hi = global sample index, stream, block).
+// stream 0 = camera ray, stream 1+b = scatter at bounce b.  Block n yields draws 2n and 2n+1.
+// A draw is 53 bits * 2^-53 in [0,1), the rand 0.8 `Standard` f64 distribution.
+RT_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += W0; k1 += W1; }
+        uint32_t h0 = __umulhi(M0, c[0]), l0 = M0 * c[0];
+        uint32_t h1 = __umulhi(M1, c[2]), l1 = M1 * c[2];
+        uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
+    }
+}
+struct Rng {
+    uint32_t k0, k1, lo, hi, stream, k; uint32_t blk[4];
+    RT_DEV Rng(uint64_t seed, uint32_t path_lo, uint32_t path_hi, uint32_t st)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), lo(path_lo), hi(path_hi), stream(st), k(0) {}
+    RT_DEV double next() {
+        if (!(k & 1)) {
+            blk[0] = lo; blk[1] = hi; blk[2] = stream; blk[3] = k >> 1;
+            philox4x32_10(blk, k0, k1);
+        }
+        uint64_t u = (k & 1) ? (((uint64_t)blk[3] << 32) | blk[2]) : (((uint64_t)blk[1] << 32) | blk[0]);
+        ++k;
+        return (double)(u >> 11) * (1.0 / 9007199254740992.0);
+    }
+    RT_DEV double range(double a, double b) { return a + (b - a) * next(); }               // rtweekend.rs:171-173
+};
+RT_DEV V3 random_in_unit_disk(Rng& g) {                                                    // vec3.rs:20-31
+    for (;;) {
+        double a = g.range(-1.0, 1.0);
+        double b = g.range(-1.0, 1.0);
+        V3 p = v3(a, b, 0.0);
+        if (length_squared(p) < 1.0) return p;
+    }
+}
+RT_DEV V3 random_unit(Rng& g) {                                                            // vec3.rs:33-41
+    for (;;) {
+        double a = g.range(-1.0, 1.0);
+        double b = g.range(-1.0, 1.0);
+        double c = g.range(-1.0, 1.0);
+        V3 p = v3(a, b, c);
+        double lsq = length_squared(p);
+        if (1e-160 < lsq && lsq <= 1.0) return p / sqrt(lsq);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device scene records.
+struct __align__(16) DPrim {       // 80 B: one Hittable (sphere.rs:13-17 / triangle.rs:12-18)
+    double v[9];                   // sphere: center xyz, radius.  triangle: v0, v1, v2
+    uint32_t tm;                   // bit 31 = type (1 triangle), bits 0..30 = material index
+    uint32_t orig;                 // file-order object index
+};
+struct __align__(8) DMat { double albedo[3]; double param; uint32_t type; uint32_t pad; };  // material.rs:23-25,54-57,82-84
+// 64 B BVH node (bvh.rs:35-42 flattened).  Siblings are adjacent (bvh.rs:167-168: left = ptr+1, right = ptr+2).
+//   internal: a = index of the left child (right = a + 1), b = 0
+//   leaf:     a = first object (index into the BVH-ordered DPrim array), b = count | RT_LEAF
+struct __align__(16) DNode { double mn[3]; double mx[3]; uint32_t a, b, pad0, pad1; };
+#define RT_LEAF 0x80000000u
+
+// The part of HitRecord (hittable.rs:13-21) that survives a hit() call and that later code reads:
+// rec.t (read back as closest_so_far, bvh.rs:200,215 / grid.rs:164), the t at which rec.p was last written
+// (rec.p == at(tp)), and the last accepted primitive (fixes normal, front_face and mat).
+struct HitState { double t; double tp; int32_t prim; };
+
+// sphere.rs:27-56.  Writes the record only on success.
+RT_DEV bool hit_sphere(const DPrim& s, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    V3 center = v3(s.v[0], s.v[1], s.v[2]);
+    double radius = s.v[3];
+    V3 oc = center - o;
+    double a = length_squared(d);
+    double h = dot(d, oc);
+    double c = length_squared(oc) - radius * radius;
+    double discriminant = h * h - a * c;
+    if (discriminant < 0.0) return false;
+    double sq = sqrt(discriminant);
+    double root = (h - sq) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (h + sq) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    rec.t = root; rec.tp = root; rec.prim = index;
+    return true;
+}
+// triangle.rs:37-81, quirks included: the interval is tested against n.d (:44-47), rec.t is written before
+// acceptance (:52), rec.p is written once t >= 0 (:59), and only then the three edge tests run (:62-75).
+RT_DEV bool hit_triangle(const DPrim& tr, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    V3 v0 = v3(tr.v[0], tr.v[1], tr.v[2]), v1 = v3(tr.v[3], tr.v[4], tr.v[5]), v2 = v3(tr.v[6], tr.v[7], tr.v[8]);
+    V3 v0v1 = v1 - v0;
+    V3 v0v2 = v2 - v0;
+    V3 n = cross(v0v1, v0v2);
+    double n_dot_dir = dot(n, d);
+    if (!(tmin < n_dot_dir && n_dot_dir < tmax)) return false;
+    double dd = -dot(n, v0);
+    double t = -(dot(n, o) + dd) / n_dot_dir;
+    rec.t = t;
+    if (t < 0.0) return false;
+    rec.tp = t;
+    V3 p = o + (t * d);
+    V3 v0p = p - v0;
+    if (dot(n, cross(v0v1, v0p)) <= 0.0) return false;
+    V3 v1v2 = v2 - v1;
+    V3 v1p = p - v1;
+    if (dot(n, cross(v1v2, v1p)) <= 0.0) return false;
+    V3 v2v0 = v0 - v2;
+    V3 v2p = p - v2;
+    if (dot(n, cross(v2v0, v2p)) <= 0.0) return false;
+    rec.prim = index;
+    return true;
+}
+RT_DEV bool hit_prim(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    return (p.tm >> 31) ? hit_triangle(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
+}
+
+// AABB::hit (acceleration/aabb.rs:28-62) with 1/dir hoisted out (1.0/dir[axis] is a pure function of the ray,
+// so computing it once per ray gives the same bits as computing it per box, aabb.rs:34).  The per-axis
+// early return (:54) is folded into one test at the end: ray_t.min only grows and ray_t.max only shrinks, and
+// neither can become NaN (a NaN t0/t1 fails every comparison and updates nothing), so `max < min` after axis k
+// implies `max < min` after axis 2.  Returns the clipped interval.
+RT_DEV bool slab(const double* mn, const double* mx, V3 o, V3 inv, double& tmin, double& tmax) {
+    double t0, t1, lo, hi;
+    t0 = (mn[0] - o.x) * inv.x; t1 = (mx[0] - o.x) * inv.x;
+    lo = (t0 < t1) ? t0 : t1; hi = (t0 < t1) ? t1 : t0;
+    if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi;
+    t0 = (mn[1] - o.y) * inv.y; t1 = (mx[1] - o.y) * inv.y;
+    lo = (t0 < t1) ? t0 : t1; hi = (t0 < t1) ? t1 : t0;
+    if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi;
+    t0 = (mn[2] - o.z) * inv.z; t1 = (mx[2] - o.z) * inv.z;
+    lo = (t0 < t1) ? t0 : t1; hi = (t0 < t1) ? t1 : t0;
+    if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi;
+    return !(tmax < tmin);
+}
+
+// value/material.rs:120-124; powi(5) expands to x * ((x*x)*(x*x))
+RT_DEV double reflectance(double cosine, double refraction_index) {
+    double r0 = (1.0 - refraction_index) / (1.0 + refraction_index);
+    r0 = r0 * r0;
+    double x = 1.0 - cosine;
+    double x2 = x * x;
+    double x4 = x2 * x2;
+    return r0 + (1.0 - r0) * (x * x4);
+}

@@ -1,0 +1,39 @@
+// rt_kernels.h — kernel argument structs shared by rt_kernels.hip and rt_api.hip
+#pragma once
+#include "rt_device.h"
+
+#define RT_BLOCK 128          // two wave64 per workgroup
+
+// SoA ray queue in HBM: one entry per live path (origin, direction, throughput, path id)
+struct RayQ { double *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb; uint32_t* id; };
+
+// where extend writes its result; trace != 0 selects the parity-entry format (rt_trace)
+struct ExtendOut { int32_t* prim; double* t; double* tp; uint8_t* hit; int trace; };
+
+// continuation of BvhNode::hit (bvh.rs:210-223): the pending far child and its entry distance
+struct __align__(16) StackEntry { double far_d; uint32_t a, b; };
+
+struct DCamera { uint32_t W, H; V3 center, pixel00, du, dv, ddu, ddv; double defocus_angle; };
+
+struct DGrid {
+    V3 box_size, origin, end, total_size; uint64_t n_cells; uint32_t max_depth;
+    const double* cell_aabb; const uint64_t* cell_offset; const uint32_t* prim_list;
+};
+
+enum { ST_SCATTER = 0, ST_BOX, ST_PRIM, ST_STEPS, ST_OVERLAP, ST_GRIDBOX, ST_SEGMENTS, ST_N };
+
+__global__ void k_generate(DCamera cam, uint32_t s_base, uint32_t s_count, uint64_t seed, RayQ out, uint32_t* count_out);
+__global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, const uint32_t* pi, const uint32_t* pj,
+                                uint64_t n, double* orig, double* dir);
+__global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
+                             double tmin0, double tmax0, ExtendOut out, StackEntry* stack, unsigned long long* stats);
+__global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
+                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
+__global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
+                              double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
+__global__ void k_shade(const DPrim* prims, const DMat* mats, RayQ in, const uint32_t* count_in,
+                        const int32_t* hit_prim_, const double* hit_tp, RayQ out, uint32_t* count_out,
+                        double* rad, uint32_t WH, uint32_t s_base, uint32_t bounce, uint32_t max_depth, uint64_t seed,
+                        unsigned long long* stats);
+__global__ void k_accumulate(const double* rad, uint32_t WH, uint32_t s_count, double* fb, int first_batch);
+__global__ void k_load_rays(const double* orig, const double* dir, uint64_t n, RayQ q);

@@ -1,0 +1,458 @@
+// rt_kernels.hip — wavefront path-tracing kernels for gfx950 (MI355X): generate, extend (BVH / grid /
+// naive), shade (+ wave64 ballot/prefix-sum compaction into the next queue) and resolve.
+//
+// Queues are SoA arrays of f64 in HBM; one lane owns one path.  All kernels are launched with a fixed
+// grid and stride over `*count` (read from device memory), so the host never has to know a queue length
+// to launch, and blocks that share an XCD (blockIdx % 8, observed round-robin placement) take contiguous
+// chunks of the queue so that coherent rays meet in the same L2.
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+RT_DEV uint32_t xcd_chunk(uint32_t b, uint32_t nb) {
+    // blocks b and b+8 share an XCD: give each XCD a contiguous range of chunks (bijective for nb % 8 == 0)
+    return (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
+}
+RT_DEV uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+RT_DEV void stat_add(unsigned long long* stats, int slot, uint64_t v) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[slot], (unsigned long long)v);
+}
+// wave64 compaction: returns the output index for lanes with `alive`, one atomic per wave
+RT_DEV uint32_t compact_slot(bool alive, uint32_t* counter) {
+    unsigned long long mask = __ballot(alive);
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if (alive && (int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader < 0 ? 0 : leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate: Camera::get_ray (camera.rs:132-148), sample_square (:189-191), defocus_disk_sample (:145-148).
+// One lane per (pixel, local sample); a wave covers an 8x8 pixel tile so primary rays stay coherent.
+// Path id = s_local * W*H + (j*W + i); RNG path = (j*W+i, s_base + s_local), stream 0.
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, uint32_t s_base, uint32_t s_count, uint64_t seed,
+                                                       RayQ out, uint32_t* count_out) {
+    const uint32_t W = cam.W, H = cam.H;
+    const uint32_t tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const uint64_t n_waves = (uint64_t)tiles_x * tiles_y * s_count;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_stride = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t w = wave0; w < n_waves; w += wave_stride) {
+        uint32_t s_local = (uint32_t)(w / ((uint64_t)tiles_x * tiles_y));
+        uint32_t tile = (uint32_t)(w % ((uint64_t)tiles_x * tiles_y));
+        uint32_t i = (tile % tiles_x) * 8 + (lane & 7), j = (tile / tiles_x) * 8 + (lane >> 3);
+        bool valid = i < W && j < H;
+        V3 orig = v3(0, 0, 0), dir = v3(0, 0, 0);
+        uint32_t pix = j * W + i;
+        if (valid) {
+            Rng g(seed, pix, s_base + s_local, 0);
+            double ox = g.next() - 0.5;
+            double oy = g.next() - 0.5;
+            V3 pixel_sample = cam.pixel00 + (((double)i + ox) * cam.du) + (((double)j + oy) * cam.dv);
+            if (cam.defocus_angle <= 0.0) {
+                orig = cam.center;
+            } else {
+                V3 p = random_in_unit_disk(g);
+                orig = cam.center + (p.x * cam.ddu) + (p.y * cam.ddv);
+            }
+            dir = pixel_sample - orig;
+        }
+        uint32_t q = compact_slot(valid, count_out);
+        if (valid) {
+            out.ox[q] = orig.x; out.oy[q] = orig.y; out.oz[q] = orig.z;
+            out.dx[q] = dir.x; out.dy[q] = dir.y; out.dz[q] = dir.z;
+            out.tr[q] = 1.0; out.tg[q] = 1.0; out.tb[q] = 1.0;
+            out.id[q] = s_local * (W * H) + pix;
+        }
+    }
+}
+
+// parity entry for get_ray: explicit pixel lists, AoS output, no queue
+__global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, const uint32_t* pi, const uint32_t* pj,
+                                uint64_t n, double* orig, double* dir) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t i = pi[k], j = pj[k];
+    Rng g(seed, j * cam.W + i, sample, 0);
+    double ox = g.next() - 0.5;
+    double oy = g.next() - 0.5;
+    V3 pixel_sample = cam.pixel00 + (((double)i + ox) * cam.du) + (((double)j + oy) * cam.dv);
+    V3 o;
+    if (cam.defocus_angle <= 0.0) o = cam.center;
+    else { V3 p = random_in_unit_disk(g); o = cam.center + (p.x * cam.ddu) + (p.y * cam.ddv); }
+    V3 d = pixel_sample - o;
+    orig[3 * k] = o.x; orig[3 * k + 1] = o.y; orig[3 * k + 2] = o.z;
+    dir[3 * k] = d.x; dir[3 * k + 1] = d.y; dir[3 * k + 2] = d.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// extend, common epilogue.  Render mode stores (hit ? prim : -1, tp); trace mode also stores rec.t and the
+// boolean, and maps the primitive back to its file-order index.
+RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState& rec, const DPrim* prims) {
+    if (out.trace) {
+        if (out.prim) out.prim[q] = rec.prim >= 0 ? (int32_t)prims[rec.prim].orig : -1;
+        if (out.t) out.t[q] = rec.t;
+        if (out.tp) out.tp[q] = rec.tp;
+        if (out.hit) out.hit[q] = hit ? 1 : 0;
+    } else {
+        out.prim[q] = hit ? rec.prim : -1;
+        out.tp[q] = rec.tp;
+    }
+}
+
+// extend_bvh: HittableList::hit, BVH arm (hittable_list.rs:81-93) = BvhNode::hit_aabb on the root
+// (bvh.rs:182-185) followed by the ordered recursive BvhNode::hit (bvh.rs:189-233), run as an explicit
+// continuation machine.  Recursion state that the reference keeps on the call stack:
+//   * the frame's ray_t.max: only ever replaced by rec.t when a `far` child is entered after the `close`
+//     child returned true (bvh.rs:215-219); if `close` returned false no frame below it changed it, so one
+//     register (`tmax`) suffices and nothing needs saving;
+//   * "did close.hit() return true": a subtree returns true iff some primitive test inside it succeeded, so a
+//     one-bit flag saved/cleared at push and OR-restored at pop reproduces it;
+//   * the pending far child and its entry distance (bvh.rs:210-212): the 16-byte stack entry.
+// The stack lives in HBM as stack[level][thread] (coalesced across the wave); `stack_cap` is the tree depth.
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
+                                                         RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+                                                         double tmin0, double tmax0, ExtendOut out,
+                                                         StackEntry* __restrict__ stack, unsigned long long* stats) {
+    const uint64_t n = count ? (uint64_t)*count : n_fixed;
+    const uint32_t nb = gridDim.x, T = nb * RT_BLOCK;
+    const uint32_t tid = xcd_chunk(blockIdx.x, nb) * RT_BLOCK + threadIdx.x;
+    StackEntry* my_stack = stack + tid;
+    uint64_t c_box = 0, c_prim = 0, c_steps = 0, c_overlap = 0, c_rays = 0;
+
+    for (uint64_t q = tid; q < n; q += T) {
+        V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
+        V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
+        V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.prim = -1;
+        ++c_rays;
+
+        DNode root = nodes[0];
+        double tmax = tmax0;
+        ++c_box;
+        double e0 = tmin0, e1 = tmax0;
+        bool go = slab(root.mn, root.mx, o, inv, e0, e1);
+        uint32_t cur_a = root.a, cur_b = root.b;
+        uint32_t sp = 0;
+        bool flag = false, need_pop = false;
+        while (go) {
+            if (need_pop) {
+                if (sp == 0) break;
+                --sp;
+                StackEntry e = my_stack[(uint64_t)sp * T];
+                bool close_hit = flag;
+                flag = flag | (e.b >> 30 & 1u);
+                if (close_hit) {                         // bvh.rs:213-222
+                    if (e.far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = e.a; cur_b = e.b & ~0x40000000u; need_pop = false; }
+                } else {                                 // bvh.rs:223
+                    cur_a = e.a; cur_b = e.b & ~0x40000000u; need_pop = false;
+                }
+                continue;
+            }
+            ++c_steps;                                   // bvh.rs:190
+            if (cur_b & RT_LEAF) {                       // bvh.rs:195-202
+                uint32_t first = cur_a, cnt = cur_b & 0x3fffffffu;
+                double closest = tmax;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    ++c_prim;
+                    DPrim P = prims[first + k];
+                    if (hit_prim(P, (int32_t)(first + k), o, d, tmin0, closest, rec)) { flag = true; closest = rec.t; }
+                }
+                need_pop = true;
+            } else {                                     // bvh.rs:203-229
+                DNode L = nodes[cur_a], R = nodes[cur_a + 1];
+                c_box += 2;
+                double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
+                bool lh = slab(L.mn, L.mx, o, inv, ld, lx);
+                bool rh = slab(R.mn, R.mx, o, inv, rd, rx);
+                if (lh && rh) {
+                    bool right_first = ld >= rd;         // bvh.rs:210-211 (tie -> right is `close`)
+                    StackEntry e;
+                    e.far_d = fmax(ld, rd);
+                    e.a = right_first ? L.a : R.a;
+                    e.b = (right_first ? L.b : R.b) | (flag ? 0x40000000u : 0u);
+                    my_stack[(uint64_t)sp * T] = e;
+                    ++sp;
+                    flag = false;
+                    cur_a = right_first ? R.a : L.a; cur_b = right_first ? R.b : L.b;
+                } else if (lh) { cur_a = L.a; cur_b = L.b; }
+                else if (rh) { cur_a = R.a; cur_b = R.b; }
+                else need_pop = true;
+            }
+        }
+        store_hit(out, q, rec.prim >= 0, rec, prims);
+    }
+    if (stats) {
+        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
+        stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
+    }
+}
+
+// extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, uint32_t n_prims,
+                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+                                                           double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
+    const uint64_t n = count ? (uint64_t)*count : n_fixed;
+    const uint32_t nb = gridDim.x, T = nb * RT_BLOCK;
+    const uint32_t tid = xcd_chunk(blockIdx.x, nb) * RT_BLOCK + threadIdx.x;
+    uint64_t c_prim = 0, c_rays = 0;
+    for (uint64_t q = tid; q < n; q += T) {
+        V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
+        V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.prim = -1;
+        double closest = tmax0;
+        ++c_rays;
+        for (uint32_t k = 0; k < n_prims; ++k) {
+            ++c_prim;
+            DPrim P = prims[k];
+            if (hit_prim(P, (int32_t)k, o, d, tmin0, closest, rec)) closest = rec.t;
+        }
+        store_hit(out, q, rec.prim >= 0, rec, prims);
+    }
+    if (stats) { stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_SEGMENTS, c_rays); }
+}
+
+// ---- grid helpers: Rust's saturating float->int casts and Grid::get_index (grid.rs:64-73)
+RT_DEV uint64_t sat_usize(double x) {
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)x;
+}
+RT_DEV int32_t sat_i32(double x) {
+    if (x != x) return 0;
+    if (x <= -2147483648.0) return (int32_t)0x80000000;
+    if (x >= 2147483647.0) return 0x7fffffff;
+    return (int32_t)x;
+}
+RT_DEV uint64_t grid_index(V3 p, const DGrid& g) {
+    uint64_t x = sat_usize(p.x / g.box_size.x);
+    uint64_t y = sat_usize(p.y / g.box_size.y);
+    uint64_t z = sat_usize(p.z / g.box_size.z);
+    double size_x = g.total_size.x / g.box_size.x;
+    double size_y = g.total_size.y / g.box_size.y;
+    return sat_usize((double)x + (double)y * size_x + (double)z * size_x * size_y);
+}
+RT_DEV uint64_t grid_cell_from_point(V3 p, const DGrid& g) {            // grid.rs:195-206 (i32 subtraction wraps)
+    int32_t dx = (int32_t)((uint32_t)sat_i32(floor(p.x)) - (uint32_t)sat_i32(g.origin.x));
+    int32_t dy = (int32_t)((uint32_t)sat_i32(floor(p.y)) - (uint32_t)sat_i32(g.origin.y));
+    int32_t dz = (int32_t)((uint32_t)sat_i32(floor(p.z)) - (uint32_t)sat_i32(g.origin.z));
+    double x = floor((double)dx / g.box_size.x) * g.box_size.x;
+    double y = floor((double)dy / g.box_size.y) * g.box_size.y;
+    double z = floor((double)dz / g.box_size.z) * g.box_size.z;
+    return grid_index(v3(floor(x), floor(y), floor(z)), g);
+}
+
+// extend_grid: HittableList::hit, grid arm (hittable_list.rs:94-100) = Grid::hit (grid.rs:139-147):
+// get_box_enter (:119-129) then the tail-recursive traverse (:151-183) as a loop.
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* __restrict__ prims,
+                                                          RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+                                                          double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
+    const uint64_t n = count ? (uint64_t)*count : n_fixed;
+    const uint32_t nb = gridDim.x, T = nb * RT_BLOCK;
+    const uint32_t tid = xcd_chunk(blockIdx.x, nb) * RT_BLOCK + threadIdx.x;
+    const double INF = __builtin_huge_val();
+    uint64_t c_box = 0, c_prim = 0, c_steps = 0, c_gbox = 0, c_rays = 0;
+    for (uint64_t q = tid; q < n; q += T) {
+        V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
+        V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
+        V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.prim = -1;
+        bool hit = false;
+        ++c_rays;
+        // get_box_enter
+        uint64_t cell = grid_cell_from_point(o, g);
+        bool have = cell < g.n_cells;
+        if (!have) {
+            // AABB::enter_and_exit (aabb.rs:65-88) on the outer box with Interval(0.001, inf); `<=` per axis
+            double mn[3] = {g.origin.x, g.origin.y, g.origin.z}, mx[3] = {g.end.x, g.end.y, g.end.z};
+            double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+            double a = 0.001, b = INF; bool ok = true;
+            for (int ax = 0; ax < 3; ++ax) {
+                double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
+                if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) b = t1; }
+                else { if (t1 > a) a = t1; if (t0 < b) b = t0; }
+                if (b <= a) { ok = false; break; }
+            }
+            if (ok) {
+                V3 point = o + d * a;                                  // grid.rs:132-136
+                cell = grid_cell_from_point(point, g);
+                have = cell < g.n_cells;
+            }
+        }
+        // traverse
+        for (uint32_t depth = 0; have; ++depth) {
+            if (depth > g.max_depth) break;                            // grid.rs:152
+            ++c_steps;
+            const double* cb = g.cell_aabb + cell * 6;
+            double mn[3] = {cb[0], cb[1], cb[2]}, mx[3] = {cb[3], cb[4], cb[5]};
+            // AABB::hit with Interval::universe (aabb.rs:28-62) keeping the Exit
+            double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+            double a = -INF, b = INF; int ex_axis = 0, ex_dir = 0; bool ok = true;
+            for (int ax = 0; ax < 3; ++ax) {
+                double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
+                if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) { b = t1; ex_axis = ax; ex_dir = 1; } }
+                else { if (t1 > a) a = t1; if (t0 < b) { b = t0; ex_axis = ax; ex_dir = -1; } }
+                if (b < a) { ok = false; break; }
+            }
+            if (!ok) break;                                            // grid.rs:155-156
+            // GridBox::hit on a copy of rec (grid.rs:160-167, 281-294)
+            ++c_gbox;
+            HitState copy = rec;
+            bool any = false;
+            double closest = tmax0;
+            uint64_t lo = g.cell_offset[cell], hi = g.cell_offset[cell + 1];
+            for (uint64_t k = lo; k < hi; ++k) {
+                ++c_prim;
+                uint32_t pi = g.prim_list[k];
+                DPrim P = prims[pi];
+                if (hit_prim(P, (int32_t)pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+            }
+            if (any) {
+                rec = copy;
+                if (rec.t <= b) { hit = true; break; }
+            }
+            ++c_box;                                                   // grid.rs:172
+            V3 step = v3(0, 0, 0);                                     // aabb.rs:161-165
+            double sv = (double)ex_dir * (ex_axis == 0 ? g.box_size.x : (ex_axis == 1 ? g.box_size.y : g.box_size.z));
+            if (ex_axis == 0) step.x = sv; else if (ex_axis == 1) step.y = sv; else step.z = sv;
+            V3 next_xyz = v3(mn[0], mn[1], mn[2]) + step;
+            bool inside = g.origin.x <= next_xyz.x && g.end.x >= next_xyz.x && g.origin.y <= next_xyz.y && g.end.y >= next_xyz.y
+                       && g.origin.z <= next_xyz.z && g.end.z >= next_xyz.z;   // grid.rs:186-192
+            if (!inside) break;
+            cell = grid_index(next_xyz - g.origin, g);                 // grid.rs:76-83
+            if (cell >= g.n_cells) break;
+        }
+        store_hit(out, q, hit, rec, prims);
+    }
+    if (stats) {
+        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
+        stat_add(stats, ST_GRIDBOX, c_gbox); stat_add(stats, ST_SEGMENTS, c_rays);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: the body of ray_color after world.hit (camera.rs:161-185) for one bounce, iteratively:
+//   miss            -> radiance = throughput * sky (camera.rs:182-184), path ends
+//   hit, no scatter -> radiance = 0 (camera.rs:176), path ends
+//   hit, scatter    -> scatter_rays++ (camera.rs:171); throughput *= attenuation; if this was the last
+//                      allowed bounce the child call returns black (camera.rs:155-157), else the scattered
+//                      ray is appended to the next queue (wave ballot + prefix sum, one atomic per wave).
+// The hit record is rebuilt from (prim, tp): rec.p = at(tp) (sphere.rs:50, triangle.rs:59), the outward
+// normal and front_face as sphere.rs:51-52 / triangle.rs:39-41,77 compute them.
+// The throughput is a left-to-right product where the reference nests right-to-left (camera.rs:172):
+// radiance may differ from the reference's in the last ulps; hit/miss decisions are unaffected.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
+                                                    RayQ in, const uint32_t* __restrict__ count_in,
+                                                    const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp,
+                                                    RayQ out, uint32_t* count_out,
+                                                    double* __restrict__ rad, uint32_t WH, uint32_t s_base,
+                                                    uint32_t bounce, uint32_t max_depth, uint64_t seed,
+                                                    unsigned long long* stats) {
+    const uint64_t n = (uint64_t)*count_in;
+    const uint32_t T = gridDim.x * RT_BLOCK;
+    const uint32_t tid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t c_scatter = 0;
+    for (uint64_t base = tid - lane; base < n; base += T) {
+        const uint64_t q = base + lane;
+        const bool valid = q < n;
+        bool alive = false;
+        V3 no = v3(0, 0, 0), nd = v3(0, 0, 0), thr = v3(0, 0, 0);
+        uint32_t id = 0;
+        if (valid) {
+            V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
+            V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
+            thr = v3(in.tr[q], in.tg[q], in.tb[q]);
+            id = in.id[q];
+            int32_t pi = hit_prim_[q];
+            V3 radiance = v3(0, 0, 0);
+            if (pi < 0) {                                             // camera.rs:182-184
+                V3 unit_direction = unit(d);
+                double a = 0.5 * (unit_direction.y + 1.0);
+                V3 sky = (1.0 - a) * v3(1.0, 1.0, 1.0) + a * v3(0.5, 0.7, 1.0);
+                radiance = thr * sky;
+            } else {
+                DPrim P = prims[pi];
+                double tp = hit_tp[q];
+                V3 p = o + (tp * d);
+                V3 outward;
+                if (P.tm >> 31) {
+                    V3 v0 = v3(P.v[0], P.v[1], P.v[2]), v1 = v3(P.v[3], P.v[4], P.v[5]), v2 = v3(P.v[6], P.v[7], P.v[8]);
+                    outward = cross(v1 - v0, v2 - v0);
+                } else {
+                    outward = (p - v3(P.v[0], P.v[1], P.v[2])) / P.v[3];
+                }
+                bool front_face = dot(d, outward) < 0.0;              // hittable.rs:26-29
+                V3 normal = front_face ? outward : -outward;
+                DMat m = mats[P.tm & 0x7fffffffu];
+                Rng g(seed, id % WH, s_base + id / WH, 1u + bounce);
+                V3 attenuation; bool scattered;
+                if (m.type == 0) {                                    // Lambertian material.rs:35-46
+                    V3 sd = normal + random_unit(g);
+                    if (near_zero(sd)) sd = normal;
+                    nd = sd; attenuation = v3(m.albedo[0], m.albedo[1], m.albedo[2]); scattered = true;
+                } else if (m.type == 1) {                             // Metal material.rs:67-74
+                    V3 reflected = reflect(d, normal);
+                    reflected = unit(reflected) + (m.param * random_unit(g));
+                    nd = reflected; attenuation = v3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                    scattered = dot(nd, normal) > 0.0;
+                } else {                                              // Dielectric material.rs:94-113
+                    attenuation = v3(1.0, 1.0, 1.0);
+                    double ri = front_face ? 1.0 / m.param : m.param;
+                    V3 unit_direction = unit(d);
+                    double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
+                    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                    if (ri * sin_theta > 1.0 || reflectance(cos_theta, ri) > g.next()) nd = reflect(unit_direction, normal);
+                    else nd = refract(unit_direction, normal, ri);
+                    scattered = true;
+                }
+                if (scattered) {
+                    ++c_scatter;
+                    thr = thr * attenuation;
+                    no = p;
+                    alive = (bounce + 1u < max_depth);                // else ray_color(depth == 0) returns black
+                }
+            }
+            if (!alive) {                                             // every path writes its slot exactly once
+                rad[(uint64_t)id * 3] = radiance.x; rad[(uint64_t)id * 3 + 1] = radiance.y; rad[(uint64_t)id * 3 + 2] = radiance.z;
+            }
+        }
+        uint32_t w = compact_slot(alive, count_out);
+        if (alive) {
+            out.ox[w] = no.x; out.oy[w] = no.y; out.oz[w] = no.z;
+            out.dx[w] = nd.x; out.dy[w] = nd.y; out.dz[w] = nd.z;
+            out.tr[w] = thr.x; out.tg[w] = thr.y; out.tb[w] = thr.z;
+            out.id[w] = id;
+        }
+    }
+    if (stats) stat_add(stats, ST_SCATTER, c_scatter);
+}
+
+// resolve: `pixel_color += ray_color(...)` (camera.rs:72) for the batch's samples, in sample order.
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const double* __restrict__ rad, uint32_t WH, uint32_t s_count,
+                                                         double* __restrict__ fb, int first_batch) {
+    uint64_t e = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;     // element of the W*H*3 framebuffer
+    const uint64_t N = (uint64_t)WH * 3;
+    for (; e < N; e += (uint64_t)gridDim.x * RT_BLOCK) {
+        double acc = first_batch ? 0.0 : fb[e];
+        for (uint32_t s = 0; s < s_count; ++s) acc = acc + rad[(uint64_t)s * N + e];
+        fb[e] = acc;
+    }
+}
+
+// interleaved xyz -> SoA queue (rt_trace input)
+__global__ void k_load_rays(const double* __restrict__ orig, const double* __restrict__ dir, uint64_t n, RayQ q) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    q.ox[k] = orig[3 * k]; q.oy[k] = orig[3 * k + 1]; q.oz[k] = orig[3 * k + 2];
+    q.dx[k] = dir[3 * k]; q.dy[k] = dir[3 * k + 1]; q.dz[k] = dir[3 * k + 2];
+}
