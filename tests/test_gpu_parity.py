@@ -1,0 +1,193 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/rt_hip.h) against the CPU oracle.
+
+Bar (task ③): bit-exact for hit decisions — primitive index, rec.t bits, the t of rec.p, the boolean, and every
+Data counter; radiance sums within a stated relative tolerance because the device multiplies attenuations
+left-to-right where the reference nests them right-to-left (camera.rs:172).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from raytracer_amd import Camera
+
+from .util import bits, load_world, oracle_of, random_rays, setup_pair, weekend_mixed
+
+pytestmark = pytest.mark.gpu
+
+RADIANCE_RTOL = 1e-12   # per-pixel sums; a product of <= 50 factors re-associated is within ~50 ulp
+
+
+def assert_trace_equal(g, c, what):
+    assert np.array_equal(g["hit"], c["hit"]), f"{what}: hit flags differ at {np.flatnonzero(g['hit'] != c['hit'])[:10]}"
+    assert np.array_equal(g["prim"], c["prim"]), f"{what}: primitive indices differ at {np.flatnonzero(g['prim'] != c['prim'])[:10]}"
+    assert np.array_equal(bits(g["t"]), bits(c["t"])), f"{what}: rec.t bits differ"
+    m = c["prim"] >= 0
+    assert np.array_equal(bits(g["tp"][m]), bits(c["tp"][m])), f"{what}: rec.p parameter differs"
+    for k in ("intersection_checks", "traversal_steps", "overlapping_aabb", "gridbox_intersection_checks", "box_tests", "prim_tests"):
+        assert g["stats"][k] == c["stats"][k], f"{what}: counter {k}: gpu {g['stats'][k]} oracle {c['stats'][k]}"
+
+
+def primary_rays(cam, step=1, sample=0, seed=1):
+    jj, ii = np.meshgrid(np.arange(0, cam.image_height, step), np.arange(0, cam.image_width, step), indexing="ij")
+    return ii.ravel().astype(np.uint32), jj.ravel().astype(np.uint32)
+
+
+CASES = [
+    # scene, algorithm, bvh_mode, grid_size, image width
+    ("simple_fuzzy_metal", "naive", None, None, 160),
+    ("simple_fuzzy_metal", "bvh", "sah-position", None, 160),
+    ("simple_fuzzy_metal", "bvh", "sah-plane", None, 160),
+    ("simple_fuzzy_metal", "bvh", "naive", None, 160),
+    ("simple_fuzzy_metal", "grid", None, 25, 160),
+    ("simple_fuzzy_metal", "grid", None, 5, 160),
+    ("simple_fuzzy_metal", "grid", None, 1, 96),
+    ("simple_hollow_glass", "bvh", "sah-position", None, 160),
+    ("triangle_test", "bvh", "sah-position", None, 160),
+    ("triangle_materials", "naive", None, None, 160),
+    ("triangle_materials", "bvh", "sah-position", None, 160),
+    ("triangle_materials", "bvh", "sah-plane", None, 160),
+    ("triangle_materials", "bvh", "naive", None, 160),
+    ("triangle_materials", "grid", None, 25, 160),
+    ("triangle_materials", "grid", None, 5, 160),
+    ("weekend-5-80-15", "naive", None, None, 160),
+    ("weekend-5-80-15", "bvh", "sah-position", None, 160),
+    ("weekend-5-80-15", "grid", None, 5, 160),
+    ("weekend-final", "bvh", "sah-position", None, 320),
+    ("weekend-final", "bvh", "sah-plane", None, 160),
+    ("weekend-final", "bvh", "naive", None, 160),
+    ("weekend-final", "grid", None, 25, 96),
+    ("weekend-final", "grid", None, 5, 160),
+    ("dragon_res4", "bvh", "sah-position", None, 320),
+    ("dragon_res4", "bvh", "sah-plane", None, 160),
+    ("dragon_res4", "bvh", "naive", None, 160),
+    ("dragon_res4", "grid", None, 25, 64),
+    ("dragon_res4", "grid", None, 5, 160),
+]
+
+
+@pytest.mark.parametrize("scene,algorithm,bvh_mode,grid_size,width", CASES)
+def test_primary_and_random_hits_bit_exact(gpu, scene, algorithm, bvh_mode, grid_size, width):
+    """north_star: primary-ray hit primitive indices bit-exact against Hittable::hit on the same ray batch."""
+    w = load_world(scene)
+    big = scene.startswith("dragon") and algorithm == "bvh" and bvh_mode == "sah-position"
+    osc = setup_pair(w, algorithm, bvh_mode or "sah-position", grid_size or 25.0, oracle_own_build=not big)
+    w.upload()
+    cam = Camera(w.filename, image_width=width)
+    pi, pj = primary_rays(cam)
+    o, d = cam.get_rays(pi, pj, sample=0, seed=7)
+    oo, od = O.generate(O.camera_from_rt(cam.c), 7, 0, pi, pj)
+    assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(d), bits(od)), "get_ray differs from the oracle"
+    assert_trace_equal(w.hit(o, d), osc.trace(algorithm, o, d), f"{scene}/{algorithm} primary")
+    # incoherent rays from inside and outside the scene bounds, both interval ends finite
+    n_rand = 20000 if algorithm != "naive" or len(w) < 200 else 4000
+    ro, rd = random_rays(n_rand, 11, -15.0, 25.0)
+    assert_trace_equal(w.hit(ro, rd, 0.001, 1e9), osc.trace(algorithm, ro, rd, 0.001, 1e9), f"{scene}/{algorithm} random")
+    w.close()
+
+
+def test_bvh_layout_consumed_matches_oracle_build(gpu):
+    """north_star: the flattened BVH node layout is bit-exact against the reference's SAH build (res4, literal O(N^2) oracle)."""
+    w = load_world("dragon_res4")
+    osc = setup_pair(w, "bvh", "sah-position", oracle_own_build=True)
+    nodes, order = osc.get_bvh()
+    assert nodes.tobytes() == w.bvh.nodes().tobytes()
+    assert np.array_equal(order, w.bvh.order(len(w)))
+    w.upload()
+    ro, rd = random_rays(50000, 3, -15.0, 25.0)
+    assert_trace_equal(w.hit(ro, rd), osc.trace("bvh", ro, rd), "res4 own-build")
+    w.close()
+
+
+RENDER_CASES = [
+    ("simple_fuzzy_metal", "bvh", None, 96, 8, 50),
+    ("simple_fuzzy_metal", "naive", None, 96, 4, 50),
+    ("simple_fuzzy_metal", "grid", 5, 64, 4, 50),
+    ("simple_hollow_glass", "bvh", None, 96, 8, 50),
+    ("simple_shiny_metal", "bvh", None, 96, 4, 50),
+    ("triangle_materials", "bvh", None, 96, 8, 50),
+    ("triangle_materials", "grid", 25, 64, 4, 50),
+    ("weekend-final", "bvh", None, 128, 4, 50),
+    ("weekend-final", "bvh", None, 64, 2, 3),
+    ("dragon_res4", "bvh", None, 128, 4, 50),
+    ("dragon_res4", "grid", 5, 48, 2, 50),
+    ("mixed", "bvh", None, 96, 4, 50),
+]
+
+
+@pytest.mark.parametrize("scene,algorithm,grid_size,width,spp,max_depth", RENDER_CASES)
+def test_render_matches_oracle(gpu, scene, algorithm, grid_size, width, spp, max_depth):
+    """Same seed, same counter RNG: every path takes the same decisions, so the counters are equal and the
+    per-pixel radiance sums agree to RADIANCE_RTOL; the 8-bit image is then identical up to rounding ties."""
+    w = weekend_mixed() if scene == "mixed" else load_world(scene)
+    big = scene.startswith("dragon") and algorithm == "bvh"
+    osc = setup_pair(w, algorithm, "sah-position", grid_size or 25.0, oracle_own_build=not big)
+    w.upload()
+    cam = Camera(w.filename, image_width=width, samples_per_pixel=spp, max_depth=max_depth)
+    img, st = cam.render(w, seed=5)
+    ref, cst = osc.render(O.camera_from_rt(cam.c), algorithm, 0, spp, max_depth, seed=5, nthreads=8)
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb", "gridbox_intersection_checks"):
+        assert st[k] == cst[k], f"counter {k}: gpu {st[k]} oracle {cst[k]}"
+    assert st["ray_segments"] <= st["primary_rays"] + st["scatter_rays"]
+    scale = np.maximum(np.abs(ref), 1e-300)
+    rel = np.max(np.abs(img - ref) / scale)
+    assert rel <= RADIANCE_RTOL, f"max relative radiance error {rel}"
+    a, b = cam.resolve(img), O.resolve(ref, spp)
+    assert np.mean(a != b) <= 1e-4 and np.max(np.abs(a.astype(int) - b.astype(int))) <= 1
+    w.close()
+
+
+def test_spp_split_is_independent_of_the_split(gpu):
+    """§8e: samples [0,8) rendered as 8, as 3+5, and one at a time give the same sums up to f64 association."""
+    w = load_world("triangle_materials"); w.algorithm = "bvh"; w.init(); w.upload()
+    cam = Camera(w.filename, image_width=96, samples_per_pixel=8)
+    full, st = cam.render(w, seed=9)
+    a, sa = cam.render(w, seed=9, s_begin=0, s_count=3)
+    b, sb = cam.render(w, seed=9, s_begin=3, s_count=5)
+    assert sa["scatter_rays"] + sb["scatter_rays"] == st["scatter_rays"]
+    assert np.allclose(a + b, full, rtol=1e-13, atol=0)
+    acc = np.zeros_like(full)
+    for s in range(8):
+        one, _ = cam.render(w, seed=9, s_begin=s, s_count=1)
+        acc = acc + one
+    assert np.array_equal(acc, full), "sample-ordered accumulation must be bit-identical"
+    w.close()
+
+
+def test_render_batching_does_not_change_the_image(gpu, monkeypatch):
+    w = load_world("simple_hollow_glass"); w.algorithm = "bvh"; w.init(); w.upload()
+    cam = Camera(w.filename, image_width=64, samples_per_pixel=6)
+    ref, _ = cam.render(w, seed=2)
+    one_by_one = np.zeros_like(ref)
+    for s in range(6):
+        img, _ = cam.render(w, seed=2, s_begin=s, s_count=1)
+        one_by_one += img
+    assert np.array_equal(ref, one_by_one)
+    w.close()
+
+
+def test_full_size_properties_weekend_final(gpu):
+    """configs[1] at full size (1920x1080; 2 of the 256 spp): size-independent properties only —
+    exact primary count, finite non-negative radiance bounded by the sky colour, and the image of samples
+    [0,2) equals image[0,1) + image[1,2)."""
+    w = load_world("weekend-final"); w.algorithm = "bvh"; w.init(); w.upload()
+    cam = Camera(w.filename, image_width=1920, samples_per_pixel=2)
+    assert (cam.image_width, cam.image_height) == (1920, 1080)
+    img, st = cam.render(w, seed=1)
+    assert st["primary_rays"] == 1920 * 1080 * 2
+    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 2.0 * 1.0 + 1e-9
+    a, _ = cam.render(w, seed=1, s_begin=0, s_count=1)
+    b, _ = cam.render(w, seed=1, s_begin=1, s_count=1)
+    assert np.array_equal(a + b, img)
+    w.close()
+
+
+def test_errors_are_reported_not_crashed(gpu):
+    from raytracer_amd import RtError
+    w = load_world("triangle_test")
+    w.upload()
+    with pytest.raises(RtError):
+        w.hit(np.zeros((1, 3)), np.ones((1, 3)), algorithm="bvh")      # reference: "Please run HittableList.init() first"
+    with pytest.raises(RtError):
+        w.hit(np.zeros((1, 3)), np.ones((1, 3)), algorithm="grid")
+    assert w.hit(np.zeros((0, 3)), np.zeros((0, 3)), algorithm="naive")["prim"].shape == (0,)
+    w.close()

@@ -1,0 +1,66 @@
+"""Shared helpers for the tests: scene handles on both sides (product host library / CPU oracle)."""
+import numpy as np
+
+from oracle import oracle_py as O
+from raytracer_amd import Camera, HittableList
+
+SCENES = {
+    "simple_fuzzy_metal": ("scenes/simple_fuzzy_metal.json", "json"),
+    "simple_shiny_metal": ("scenes/simple_shiny_metal.json", "json"),
+    "simple_hollow_glass": ("scenes/simple_hollow_glass.json", "json"),
+    "triangle_test": ("scenes/triangle_test.json", "json"),
+    "triangle_materials": ("scenes/triangle_materials.json", "json"),
+    "weekend-1-50-25": ("scenes/weekend-1-50-25.json", "json"),
+    "weekend-5-80-15": ("scenes/weekend-5-80-15.json", "json"),
+    "weekend-final": ("scenes/weekend-final.json", "json"),
+    "dragon_res4": ("scenes/dragon_recon/dragon_vrip_res4.ply", "ply"),
+    "dragon_res3": ("scenes/dragon_recon/dragon_vrip_res3.ply", "ply"),
+}
+
+
+def load_world(name):
+    path, fmt = SCENES[name]
+    return HittableList.from_json(path) if fmt == "json" else HittableList.from_ply(path)
+
+
+def weekend_mixed():
+    """Config 5: triangle_materials.json appended to weekend-final.json (493 objects); 'weekend' camera preset."""
+    w = HittableList.from_json("scenes/weekend-final.json")
+    w.append(HittableList.from_json("scenes/triangle_materials.json"))
+    w.filename = "scenes/weekend-mixed.json"
+    return w
+
+
+def oracle_of(world):
+    return O.OracleScene(world.prims(), world.centroids(), world.materials())
+
+
+def setup_pair(world, algorithm, bvh_mode="sah-position", grid_size=25.0, oracle_own_build=True):
+    """init() the product world and an oracle twin with the same acceleration structure settings."""
+    world.algorithm, world.bvh_mode, world.grid_size = algorithm, bvh_mode, grid_size
+    world.init()
+    osc = oracle_of(world)
+    if algorithm == "bvh":
+        if oracle_own_build:
+            osc.build_bvh(bvh_mode)
+        else:  # scenes too big for the oracle's literal O(N^2) builder: import the (separately pinned) layout
+            osc.set_bvh(world.bvh.nodes(), world.bvh.order(len(world)))
+    elif algorithm == "grid":
+        osc.build_grid(grid_size)
+    return osc
+
+
+def random_rays(n, seed, lo=-30.0, hi=30.0):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    return o, d
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
