@@ -47,7 +47,7 @@ struct Workspace {
     uint32_t depth_cap = 0;      // entries in `counts`
     double* qbuf[2] = {nullptr, nullptr};   // 9 doubles per path each
     uint32_t* qid[2] = {nullptr, nullptr};
-    int32_t* hit_prim = nullptr; double* hit_tp = nullptr;
+    int32_t* hit_prim = nullptr; double* hit_tp = nullptr; double* hit_tn = nullptr;
     double* rad = nullptr;
     uint32_t* counts = nullptr;
     unsigned long long* stats = nullptr;
@@ -55,10 +55,10 @@ struct Workspace {
     unsigned long long* h_stats = nullptr;
     void release() {
         for (int i = 0; i < 2; ++i) { if (qbuf[i]) (void)hipFree(qbuf[i]); if (qid[i]) (void)hipFree(qid[i]); qbuf[i] = nullptr; qid[i] = nullptr; }
-        if (hit_prim) (void)hipFree(hit_prim); if (hit_tp) (void)hipFree(hit_tp); if (rad) (void)hipFree(rad);
+        if (hit_prim) (void)hipFree(hit_prim); if (hit_tp) (void)hipFree(hit_tp); if (hit_tn) (void)hipFree(hit_tn); if (rad) (void)hipFree(rad);
         if (counts) (void)hipFree(counts); if (stats) (void)hipFree(stats);
         if (h_count) (void)hipHostFree(h_count); if (h_stats) (void)hipHostFree(h_stats);
-        hit_prim = nullptr; hit_tp = nullptr; rad = nullptr; counts = nullptr; stats = nullptr; h_count = nullptr; h_stats = nullptr;
+        hit_prim = nullptr; hit_tp = nullptr; hit_tn = nullptr; rad = nullptr; counts = nullptr; stats = nullptr; h_count = nullptr; h_stats = nullptr;
         cap = 0; depth_cap = 0;
     }
     RayQ q(int i) const {
@@ -75,6 +75,7 @@ V3 tov(const double* p) { V3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
 
 struct rt_scene {
     uint32_t n_prims = 0, n_mats = 0;
+    bool mixed = false;                // spheres and triangles together: shade needs the accept-time t as well
     std::vector<rt_prim> h_prims;
     DPrim* d_prims = nullptr;          // file order (naive, grid)
     DMat* d_mats = nullptr;
@@ -108,6 +109,7 @@ int ensure_workspace(rt_scene* sc, uint64_t cap, uint32_t depth_cap) {
     }
     HIPCHECK(hipMalloc(&w.hit_prim, cap * sizeof(int32_t)));
     HIPCHECK(hipMalloc(&w.hit_tp, cap * sizeof(double)));
+    HIPCHECK(hipMalloc(&w.hit_tn, cap * sizeof(double)));
     HIPCHECK(hipMalloc(&w.rad, cap * 3 * sizeof(double)));
     HIPCHECK(hipMalloc(&w.counts, (size_t)depth_cap * sizeof(uint32_t)));
     HIPCHECK(hipMalloc(&w.stats, ST_N * sizeof(unsigned long long)));
@@ -194,13 +196,13 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, s_begin + s0, kb, seed, w.q(0), w.counts);
         end_span();
         for (uint32_t b = 0; b < max_depth; ++b) {
-            ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.hit = nullptr; eo.trace = 0;
+            ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.tn = sc->mixed ? w.hit_tn : nullptr; eo.hit = nullptr; eo.trace = 0;
             begin_span(K_EXTEND);
             rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, st);
             if (rc) return rc;
             end_span(); ++extend_launches;
             begin_span(K_SHADE);
-            hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp,
+            hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
                                w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, b, max_depth, seed, w.stats);
             end_span();
             HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -266,6 +268,7 @@ rt_scene* rt_scene_create(const rt_prim* prims, uint32_t n_prims, const rt_mater
     rt_scene* sc = new rt_scene();
     sc->n_prims = n_prims; sc->n_mats = n_mats;
     sc->h_prims.assign(prims, prims + n_prims);
+    { bool sph = false, tri = false; for (uint32_t i = 0; i < n_prims; ++i) (prims[i].type == RT_TRIANGLE ? tri : sph) = true; sc->mixed = sph && tri; }
     std::vector<DPrim> dp(n_prims ? n_prims : 1);
     for (uint32_t i = 0; i < n_prims; ++i) dp[i] = to_dprim(prims[i], i);
     std::vector<DMat> dm(n_mats ? n_mats : 1);
@@ -388,7 +391,7 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
         if (e == hipSuccess) e = hipMemcpyAsync(d_d, dir + 3 * off, m * 3 * sizeof(double), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { ret = fail(RT_E_HIP, "ray upload failed: %s", hipGetErrorString(e)); break; }
         hipLaunchKernelGGL(k_load_rays, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_o, d_d, m, w.q(0));
-        ExtendOut eo; eo.prim = w.hit_prim; eo.t = d_t; eo.tp = w.hit_tp; eo.hit = d_h; eo.trace = 1;
+        ExtendOut eo; eo.prim = w.hit_prim; eo.t = d_t; eo.tp = w.hit_tp; eo.tn = nullptr; eo.hit = d_h; eo.trace = 1;
         ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, st);
         if (ret) break;
         if (out_prim) e = hipMemcpyAsync(out_prim + off, w.hit_prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);

@@ -100,7 +100,9 @@ struct __align__(16) DNode { double mn[3]; double mx[3]; uint32_t a, b, pad0, pa
 // The part of HitRecord (hittable.rs:13-21) that survives a hit() call and that later code reads:
 // rec.t (read back as closest_so_far, bvh.rs:200,215 / grid.rs:164), the t at which rec.p was last written
 // (rec.p == at(tp)), and the last accepted primitive (fixes normal, front_face and mat).
-struct HitState { double t; double tp; int32_t prim; };
+// `tn` is the t at which that primitive was accepted: a sphere's normal is built from the hit point of ITS
+// acceptance (sphere.rs:50-52) even if a later failed triangle test moved rec.p (triangle.rs:59).
+struct HitState { double t; double tp; double tn; int32_t prim; };
 
 // sphere.rs:27-56.  Writes the record only on success.
 RT_DEV bool hit_sphere(const DPrim& s, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
@@ -118,7 +120,7 @@ RT_DEV bool hit_sphere(const DPrim& s, int32_t index, V3 o, V3 d, double tmin, d
         root = (h + sq) / a;
         if (!(tmin < root && root < tmax)) return false;
     }
-    rec.t = root; rec.tp = root; rec.prim = index;
+    rec.t = root; rec.tp = root; rec.tn = root; rec.prim = index;
     return true;
 }
 // triangle.rs:37-81, quirks included: the interval is tested against n.d (:44-47), rec.t is written before
@@ -144,7 +146,7 @@ RT_DEV bool hit_triangle(const DPrim& tr, int32_t index, V3 o, V3 d, double tmin
     V3 v2v0 = v0 - v2;
     V3 v2p = p - v2;
     if (dot(n, cross(v2v0, v2p)) <= 0.0) return false;
-    rec.prim = index;
+    rec.prim = index; rec.tn = t;
     return true;
 }
 RT_DEV bool hit_prim(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {

@@ -8,7 +8,8 @@
 struct RayQ { double *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb; uint32_t* id; };
 
 // where extend writes its result; trace != 0 selects the parity-entry format (rt_trace)
-struct ExtendOut { int32_t* prim; double* t; double* tp; uint8_t* hit; int trace; };
+// tn (nullable) = t of the accepted primitive; only stored for scenes that mix spheres and triangles
+struct ExtendOut { int32_t* prim; double* t; double* tp; double* tn; uint8_t* hit; int trace; };
 
 // continuation of BvhNode::hit (bvh.rs:210-223): the pending far child and its entry distance
 struct __align__(16) StackEntry { double far_d; uint32_t a, b; };
@@ -32,7 +33,7 @@ __global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, co
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_shade(const DPrim* prims, const DMat* mats, RayQ in, const uint32_t* count_in,
-                        const int32_t* hit_prim_, const double* hit_tp, RayQ out, uint32_t* count_out,
+                        const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,
                         double* rad, uint32_t WH, uint32_t s_base, uint32_t bounce, uint32_t max_depth, uint64_t seed,
                         unsigned long long* stats);
 __global__ void k_accumulate(const double* rad, uint32_t WH, uint32_t s_count, double* fb, int first_batch);

@@ -106,6 +106,7 @@ RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState
     } else {
         out.prim[q] = hit ? rec.prim : -1;
         out.tp[q] = rec.tp;
+        if (out.tn) out.tn[q] = rec.tn;
     }
 }
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
         V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
         V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
         V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.prim = -1;
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
         ++c_rays;
 
         DNode root = nodes[0];
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restri
     for (uint64_t q = tid; q < n; q += T) {
         V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
         V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
-        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.prim = -1;
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
         double closest = tmax0;
         ++c_rays;
         for (uint32_t k = 0; k < n_prims; ++k) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
         V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
         V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
         V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.prim = -1;
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
         bool hit = false;
         ++c_rays;
         // get_box_enter
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
 // radiance may differ from the reference's in the last ulps; hit/miss decisions are unaffected.
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
                                                     RayQ in, const uint32_t* __restrict__ count_in,
-                                                    const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp,
+                                                    const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
                                                     double* __restrict__ rad, uint32_t WH, uint32_t s_base,
                                                     uint32_t bounce, uint32_t max_depth, uint64_t seed,
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ pr
                     V3 v0 = v3(P.v[0], P.v[1], P.v[2]), v1 = v3(P.v[3], P.v[4], P.v[5]), v2 = v3(P.v[6], P.v[7], P.v[8]);
                     outward = cross(v1 - v0, v2 - v0);
                 } else {
-                    outward = (p - v3(P.v[0], P.v[1], P.v[2])) / P.v[3];
+                    V3 pn = hit_tn ? o + (hit_tn[q] * d) : p;            // rec.p as it was when the sphere was accepted
+                    outward = (pn - v3(P.v[0], P.v[1], P.v[2])) / P.v[3];
                 }
                 bool front_face = dot(d, outward) < 0.0;              // hittable.rs:26-29
                 V3 normal = front_face ? outward : -outward;
