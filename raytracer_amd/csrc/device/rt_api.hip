@@ -29,6 +29,7 @@ hipStream_t g_stream = nullptr;
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
 uint32_t g_stream_blocks = 2048;
 uint64_t g_batch_paths = 1ull << 24;  // paths in flight per batch
+int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
 
 struct EventPool {
     std::vector<hipEvent_t> ev; size_t used = 0;
@@ -49,7 +50,7 @@ struct Workspace {
     uint32_t* qid[2] = {nullptr, nullptr};
     int32_t* hit_prim = nullptr; double* hit_tp = nullptr; double* hit_tn = nullptr;
     double* rad = nullptr;
-    uint32_t* counts = nullptr;
+    uint32_t* counts = nullptr;      // queue lengths per bounce, then (at +depth_cap) the extend kernels' fetch counters
     unsigned long long* stats = nullptr;
     uint32_t* h_count = nullptr; // pinned
     unsigned long long* h_stats = nullptr;
@@ -111,7 +112,7 @@ int ensure_workspace(rt_scene* sc, uint64_t cap, uint32_t depth_cap) {
     HIPCHECK(hipMalloc(&w.hit_tp, cap * sizeof(double)));
     HIPCHECK(hipMalloc(&w.hit_tn, cap * sizeof(double)));
     HIPCHECK(hipMalloc(&w.rad, cap * 3 * sizeof(double)));
-    HIPCHECK(hipMalloc(&w.counts, (size_t)depth_cap * sizeof(uint32_t)));
+    HIPCHECK(hipMalloc(&w.counts, (size_t)depth_cap * 2 * sizeof(uint32_t)));
     HIPCHECK(hipMalloc(&w.stats, ST_N * sizeof(unsigned long long)));
     HIPCHECK(hipHostMalloc(&w.h_count, 64));
     HIPCHECK(hipHostMalloc(&w.h_stats, ST_N * sizeof(unsigned long long)));
@@ -120,12 +121,15 @@ int ensure_workspace(rt_scene* sc, uint64_t cap, uint32_t depth_cap) {
 }
 
 int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* count, uint64_t n_fixed, double tmin, double tmax,
-                  const ExtendOut& out, hipStream_t st) {
+                  const ExtendOut& out, uint32_t* fetch_ctr, hipStream_t st) {
     dim3 grid(g_extend_blocks), block(RT_BLOCK);
     switch (algorithm) {
     case RT_ALGO_BVH:
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
-        hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+        if (g_extend_variant == 1)
+            hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+        else
+            hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, sc->ws.stats);
         break;
     case RT_ALGO_NAIVE:
         hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->n_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
@@ -191,14 +195,14 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
     if (s_count == 0) HIPCHECK(hipMemsetAsync(d_fb, 0, WH * 3 * sizeof(double), st));
     for (uint32_t s0 = 0; s0 < s_count; s0 += k) {
         const uint32_t kb = (s_count - s0 < k) ? (s_count - s0) : k;
-        HIPCHECK(hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * sizeof(uint32_t), st));
+        HIPCHECK(hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st));
         begin_span(K_GENERATE);
         hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, s_begin + s0, kb, seed, w.q(0), w.counts);
         end_span();
         for (uint32_t b = 0; b < max_depth; ++b) {
             ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.tn = sc->mixed ? w.hit_tn : nullptr; eo.hit = nullptr; eo.trace = 0;
             begin_span(K_EXTEND);
-            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, st);
+            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, w.counts + w.depth_cap + b, st);
             if (rc) return rc;
             end_span(); ++extend_launches;
             begin_span(K_SHADE);
@@ -248,6 +252,7 @@ int rt_init(int device) {
         g_device = device;
     }
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
+    if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
     g_inited = true;
     return RT_OK;
@@ -392,7 +397,8 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
         if (e != hipSuccess) { ret = fail(RT_E_HIP, "ray upload failed: %s", hipGetErrorString(e)); break; }
         hipLaunchKernelGGL(k_load_rays, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_o, d_d, m, w.q(0));
         ExtendOut eo; eo.prim = w.hit_prim; eo.t = d_t; eo.tp = w.hit_tp; eo.tn = nullptr; eo.hit = d_h; eo.trace = 1;
-        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, st);
+        if (hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st) != hipSuccess) { ret = fail(RT_E_HIP, "memset failed"); break; }
+        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, w.counts + w.depth_cap, st);
         if (ret) break;
         if (out_prim) e = hipMemcpyAsync(out_prim + off, w.hit_prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && out_t) e = hipMemcpyAsync(out_t + off, d_t, m * sizeof(double), hipMemcpyDeviceToHost, st);

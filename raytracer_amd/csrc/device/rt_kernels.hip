@@ -198,6 +198,128 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
     }
 }
 
+// extend_bvh, persistent form: the same continuation machine as k_extend_bvh (every decision, counter and
+// result is identical), restructured for a wave64 machine whose lanes finish at very different times:
+//   * a wave keeps its 64 lanes fed: when >= RT_REFILL lanes are idle it pulls fresh rays for them from the
+//     queue (one atomic per chunk of rays per wave), instead of waiting for its slowest lane;
+//   * one loop iteration = [internal-node visit for every lane] then [leaf tests and stack pops until the lane
+//     stands on an internal node again], so the expensive two-box visit always runs with all live lanes;
+//   * the continuation stack's top RT_STK entries live in LDS ([level][lane]: conflict-free for b64 and b32
+//     accesses whatever level each lane is on); deeper entries spill to HBM as stack[level][thread].
+#define RT_STK 8
+#define RT_REFILL 16
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
+                                                          RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+                                                          double tmin0, double tmax0, ExtendOut out,
+                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, unsigned long long* stats) {
+    __shared__ double s_fd[RT_STK][RT_BLOCK];
+    __shared__ uint2 s_ab[RT_STK][RT_BLOCK];
+    const uint32_t n = count ? *count : (uint32_t)n_fixed;
+    const uint32_t T = gridDim.x * RT_BLOCK, tx = threadIdx.x, lane = tx & 63;
+    StackEntry* my_spill = spill + (blockIdx.x * RT_BLOCK + tx);
+    uint32_t chunk = n / ((T >> 6) * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
+    uint32_t c_next = 0, c_end = 0;          // wave-uniform: the wave's current chunk of the queue
+    bool exhausted = false;
+    uint32_t c_box = 0, c_prim = 0, c_steps = 0, c_overlap = 0, c_rays = 0;
+
+    bool active = false;
+    uint32_t q = 0, cur_a = 0, cur_b = 0, sp = 0, lo = 0;
+    bool flag = false;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
+    double tmax = tmax0;
+    HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+    const DNode root = nodes[0];
+
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle && !exhausted && (n_idle >= RT_REFILL)) {
+            if (c_next >= c_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) { exhausted = true; c_next = c_end = n; }
+                else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
+            }
+            const uint32_t avail = c_end - c_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < avail) {
+                q = c_next + rank;
+                o = v3(in.ox[q], in.oy[q], in.oz[q]);
+                d = v3(in.dx[q], in.dy[q], in.dz[q]);
+                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+                ++c_rays; ++c_box;
+                tmax = tmax0; sp = 0; lo = 0; flag = false;
+                double e0 = tmin0, e1 = tmax0;
+                if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root.a; cur_b = root.b; }   // bvh.rs:84-85
+                else store_hit(out, q, false, rec, prims);
+            }
+            c_next += (n_idle < avail) ? n_idle : avail;
+        }
+        if (!__any(active)) { if (exhausted) break; continue; }
+
+        // ---- one internal-node visit per live lane (bvh.rs:203-229)
+        bool need_pop = false;
+        if (active && !(cur_b & RT_LEAF)) {
+            ++c_steps;                                   // bvh.rs:190
+            const DNode L = nodes[cur_a], R = nodes[cur_a + 1];
+            c_box += 2;
+            double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
+            const bool lh = slab(L.mn, L.mx, o, inv, ld, lx);
+            const bool rh = slab(R.mn, R.mx, o, inv, rd, rx);
+            if (lh && rh) {
+                const bool right_first = ld >= rd;       // bvh.rs:210-211 (tie -> right is `close`)
+                if (sp - lo == RT_STK) {                 // LDS window full: its oldest entry goes to HBM
+                    StackEntry e; const uint32_t s = lo & (RT_STK - 1);
+                    e.far_d = s_fd[s][tx]; e.a = s_ab[s][tx].x; e.b = s_ab[s][tx].y;
+                    my_spill[(uint64_t)lo * T] = e; ++lo;
+                }
+                const uint32_t s = sp & (RT_STK - 1);
+                s_fd[s][tx] = fmax(ld, rd);
+                s_ab[s][tx] = make_uint2(right_first ? L.a : R.a, (right_first ? L.b : R.b) | (flag ? 0x40000000u : 0u));
+                ++sp; flag = false;
+                cur_a = right_first ? R.a : L.a; cur_b = right_first ? R.b : L.b;
+            } else if (lh) { cur_a = L.a; cur_b = L.b; }
+            else if (rh) { cur_a = R.a; cur_b = R.b; }
+            else need_pop = true;
+        }
+        // ---- leaves and pops until the lane stands on an internal node again (or its ray is finished)
+        while (active && (need_pop || (cur_b & RT_LEAF))) {
+            if (!need_pop) {                             // bvh.rs:195-202
+                ++c_steps;
+                const uint32_t first = cur_a, cnt = cur_b & 0x3fffffffu;
+                double closest = tmax;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    ++c_prim;
+                    const DPrim P = prims[first + k];
+                    if (hit_prim(P, (int32_t)(first + k), o, d, tmin0, closest, rec)) { flag = true; closest = rec.t; }
+                }
+                need_pop = true;
+            } else if (sp == 0) {
+                store_hit(out, q, rec.prim >= 0, rec, prims);
+                active = false;
+            } else {
+                --sp;
+                double far_d; uint32_t ea, eb;
+                if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ea = e.a; eb = e.b; }
+                else { const uint32_t s = sp & (RT_STK - 1); far_d = s_fd[s][tx]; ea = s_ab[s][tx].x; eb = s_ab[s][tx].y; }
+                const bool close_hit = flag;
+                flag = flag | ((eb >> 30) & 1u);
+                if (close_hit) {                         // bvh.rs:213-222
+                    if (far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }
+                } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
+            }
+        }
+    }
+    if (stats) {
+        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
+        stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
+    }
+}
+
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, uint32_t n_prims,
                                                            RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
