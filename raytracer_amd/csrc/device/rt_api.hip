@@ -29,6 +29,7 @@ hipStream_t g_stream = nullptr;
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
 uint32_t g_stream_blocks = 2048;
 uint64_t g_batch_paths = 1ull << 24;  // paths in flight per batch
+uint32_t g_tune = (16u << 16) | (1u << 8) | 2u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
 int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
 
 struct EventPool {
@@ -129,7 +130,7 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         if (g_extend_variant == 1)
             hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
         else
-            hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, sc->ws.stats);
+            hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats);
         break;
     case RT_ALGO_NAIVE:
         hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->n_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
@@ -253,6 +254,7 @@ int rt_init(int device) {
     }
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
+    if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
     g_inited = true;
     return RT_OK;

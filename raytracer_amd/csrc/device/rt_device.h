@@ -172,6 +172,26 @@ RT_DEV bool slab(const double* mn, const double* mx, V3 o, V3 inv, double& tmin,
     return !(tmax < tmin);
 }
 
+// The same test written with v_min_f64 / v_max_f64 (4 instructions per axis instead of 11).  Identical to slab()
+// whenever no t0/t1 is NaN: lo/hi are then min/max of (t0,t1), and `if (lo > tmin) tmin = lo` is max(tmin, lo).
+// A NaN t0/t1 needs 0 * inf, i.e. a non-finite 1/dir component (dir component zero, denormal or NaN) or a
+// non-finite origin: rays for which ray_is_regular() is false must use slab().  (Signed zeros: min/max may pick
+// either zero of an equal pair; the interval ends are only ever compared, and tmin >= 0.001, so it cannot matter.)
+RT_DEV bool slab_fast(const double* mn, const double* mx, V3 o, V3 inv, double& tmin, double& tmax) {
+    double t0, t1;
+    t0 = (mn[0] - o.x) * inv.x; t1 = (mx[0] - o.x) * inv.x;
+    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    t0 = (mn[1] - o.y) * inv.y; t1 = (mx[1] - o.y) * inv.y;
+    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    t0 = (mn[2] - o.z) * inv.z; t1 = (mx[2] - o.z) * inv.z;
+    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    return !(tmax < tmin);
+}
+RT_DEV bool is_finite(double x) { return fabs(x) < __builtin_huge_val(); }     // false for inf and NaN
+RT_DEV bool ray_is_regular(V3 o, V3 inv) {
+    return is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv.x) && is_finite(inv.y) && is_finite(inv.z);
+}
+
 // value/material.rs:120-124; powi(5) expands to x * ((x*x)*(x*x))
 RT_DEV double reflectance(double cosine, double refraction_index) {
     double r0 = (1.0 - refraction_index) / (1.0 + refraction_index);

@@ -208,10 +208,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
 //     accesses whatever level each lane is on); deeper entries spill to HBM as stack[level][thread].
 #define RT_STK 8
 #define RT_REFILL 16
+#define RT_COST_INT 1u    // relative instruction cost of the two phases, for the vote
+#define RT_COST_LEAF 2u
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out,
-                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, unsigned long long* stats) {
+                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats) {
+    const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu, refill_min = (tune >> 16) & 0xffu;
     __shared__ double s_fd[RT_STK][RT_BLOCK];
     __shared__ uint2 s_ab[RT_STK][RT_BLOCK];
     const uint32_t n = count ? *count : (uint32_t)n_fixed;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
     bool exhausted = false;
     uint32_t c_box = 0, c_prim = 0, c_steps = 0, c_overlap = 0, c_rays = 0;
 
-    bool active = false;
+    bool active = false, need_pop = false, regular = true, all_regular = true;
     uint32_t q = 0, cur_a = 0, cur_b = 0, sp = 0, lo = 0;
     bool flag = false;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
         // ---- refill idle lanes
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle && !exhausted && (n_idle >= RT_REFILL)) {
+        if (n_idle && !exhausted && (n_idle >= refill_min)) {
             if (c_next >= c_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
@@ -250,45 +253,55 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
                 o = v3(in.ox[q], in.oy[q], in.oz[q]);
                 d = v3(in.dx[q], in.dy[q], in.dz[q]);
                 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                regular = ray_is_regular(o, inv);
                 rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
                 ++c_rays; ++c_box;
-                tmax = tmax0; sp = 0; lo = 0; flag = false;
+                tmax = tmax0; sp = 0; lo = 0; flag = false; need_pop = false;
                 double e0 = tmin0, e1 = tmax0;
                 if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root.a; cur_b = root.b; }   // bvh.rs:84-85
                 else store_hit(out, q, false, rec, prims);
             }
             c_next += (n_idle < avail) ? n_idle : avail;
+            all_regular = !__any(active && !regular);    // min/max box test is exact only for regular rays
         }
         if (!__any(active)) { if (exhausted) break; continue; }
 
-        // ---- one internal-node visit per live lane (bvh.rs:203-229)
-        bool need_pop = false;
-        if (active && !(cur_b & RT_LEAF)) {
-            ++c_steps;                                   // bvh.rs:190
-            const DNode L = nodes[cur_a], R = nodes[cur_a + 1];
-            c_box += 2;
-            double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
-            const bool lh = slab(L.mn, L.mx, o, inv, ld, lx);
-            const bool rh = slab(R.mn, R.mx, o, inv, rd, rx);
-            if (lh && rh) {
-                const bool right_first = ld >= rd;       // bvh.rs:210-211 (tie -> right is `close`)
-                if (sp - lo == RT_STK) {                 // LDS window full: its oldest entry goes to HBM
-                    StackEntry e; const uint32_t s = lo & (RT_STK - 1);
-                    e.far_d = s_fd[s][tx]; e.a = s_ab[s][tx].x; e.b = s_ab[s][tx].y;
-                    my_spill[(uint64_t)lo * T] = e; ++lo;
+        // ---- phase vote.  A lane is either on an internal node (wants the two-box visit) or on a leaf / waiting
+        // to pop (wants the primitive tests + stack work).  Running both every iteration leaves most lanes masked
+        // in one of them; instead the wave runs the phase that serves more lanes per instruction and the others wait.
+        const bool want_leaf = active && (need_pop || (cur_b & RT_LEAF));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
+        const uint32_t n_int = (uint32_t)__popcll(__ballot(active && !want_leaf));
+        if (n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int)) {   // never starve: one side is non-empty
+            // ---- one internal-node visit (bvh.rs:203-229), branch-free apart from the push
+            if (active && !want_leaf) {
+                ++c_steps;                               // bvh.rs:190
+                const DNode* pair = nodes + cur_a;       // siblings are adjacent: one 128-byte fetch
+                const DNode L = pair[0], R = pair[1];
+                c_box += 2;
+                double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
+                bool lh, rh;
+                if (all_regular) { lh = slab_fast(L.mn, L.mx, o, inv, ld, lx); rh = slab_fast(R.mn, R.mx, o, inv, rd, rx); }
+                else { lh = slab(L.mn, L.mx, o, inv, ld, lx); rh = slab(R.mn, R.mx, o, inv, rd, rx); }
+                const bool both = lh && rh;
+                const bool go_right = both ? (ld >= rd) : rh;      // bvh.rs:210-211 (tie -> right is `close`), :226-227
+                if (both) {
+                    if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
+                        StackEntry e; const uint32_t s = lo & (RT_STK - 1);
+                        e.far_d = s_fd[s][tx]; e.a = s_ab[s][tx].x; e.b = s_ab[s][tx].y;
+                        my_spill[(uint64_t)lo * T] = e; ++lo;
+                    }
+                    const uint32_t s = sp & (RT_STK - 1);
+                    s_fd[s][tx] = fmax(ld, rd);          // bvh.rs:212
+                    s_ab[s][tx] = make_uint2(go_right ? L.a : R.a, (go_right ? L.b : R.b) | (flag ? 0x40000000u : 0u));
+                    ++sp; flag = false;
                 }
-                const uint32_t s = sp & (RT_STK - 1);
-                s_fd[s][tx] = fmax(ld, rd);
-                s_ab[s][tx] = make_uint2(right_first ? L.a : R.a, (right_first ? L.b : R.b) | (flag ? 0x40000000u : 0u));
-                ++sp; flag = false;
-                cur_a = right_first ? R.a : L.a; cur_b = right_first ? R.b : L.b;
-            } else if (lh) { cur_a = L.a; cur_b = L.b; }
-            else if (rh) { cur_a = R.a; cur_b = R.b; }
-            else need_pop = true;
-        }
-        // ---- leaves and pops until the lane stands on an internal node again (or its ray is finished)
-        while (active && (need_pop || (cur_b & RT_LEAF))) {
-            if (!need_pop) {                             // bvh.rs:195-202
+                cur_a = go_right ? R.a : L.a; cur_b = go_right ? R.b : L.b;
+                need_pop = !(lh || rh);
+            }
+        } else if (want_leaf) {
+            // ---- leaf tests (bvh.rs:195-202), then pops until the lane has a node again or its ray is finished
+            if (!need_pop) {
                 ++c_steps;
                 const uint32_t first = cur_a, cnt = cur_b & 0x3fffffffu;
                 double closest = tmax;
@@ -298,19 +311,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
                     if (hit_prim(P, (int32_t)(first + k), o, d, tmin0, closest, rec)) { flag = true; closest = rec.t; }
                 }
                 need_pop = true;
-            } else if (sp == 0) {
-                store_hit(out, q, rec.prim >= 0, rec, prims);
-                active = false;
-            } else {
-                --sp;
-                double far_d; uint32_t ea, eb;
-                if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ea = e.a; eb = e.b; }
-                else { const uint32_t s = sp & (RT_STK - 1); far_d = s_fd[s][tx]; ea = s_ab[s][tx].x; eb = s_ab[s][tx].y; }
-                const bool close_hit = flag;
-                flag = flag | ((eb >> 30) & 1u);
-                if (close_hit) {                         // bvh.rs:213-222
-                    if (far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }
-                } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
+            }
+            while (need_pop) {
+                if (sp == 0) {
+                    store_hit(out, q, rec.prim >= 0, rec, prims);
+                    active = false; need_pop = false;
+                } else {
+                    --sp;
+                    double far_d; uint32_t ea, eb;
+                    if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ea = e.a; eb = e.b; }
+                    else { const uint32_t s = sp & (RT_STK - 1); far_d = s_fd[s][tx]; ea = s_ab[s][tx].x; eb = s_ab[s][tx].y; }
+                    const bool close_hit = flag;
+                    flag = flag | ((eb >> 30) & 1u);
+                    if (close_hit) {                     // bvh.rs:213-222
+                        if (far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }
+                    } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
+                }
             }
         }
     }
