@@ -84,12 +84,12 @@ def main():
     H, W = cam.image_height, cam.image_width
     fb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    s_begin = rank * a.spp_per_gpu
+    from raytracer_amd.dist import reduce_framebuffer, spp_range
+    s_begin, s_count = spp_range(rank, world, a.spp_per_gpu * world)
 
     def step():
-        _, st = cam.render(w, seed=1, s_begin=s_begin, s_count=a.spp_per_gpu, d_out=fb.data_ptr(), stream=stream)
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the one exchange step of the path
+        _, st = cam.render(w, seed=1, s_begin=s_begin, s_count=s_count, d_out=fb.data_ptr(), stream=stream)
+        reduce_framebuffer(fb, dst=0)                        # RCCL over xGMI: the one exchange step of the path
         return st
 
     def fence():

@@ -800,6 +800,12 @@ void orc_resolve(const double* sum, uint64_t n_pixels, uint32_t spp_total, uint8
     }
 }
 
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox4x32_10(c, key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
 double orc_rng_draw(uint64_t seed, uint32_t path_lo, uint32_t path_hi, uint32_t stream, uint32_t k) {
     Rng g(seed, path_lo, path_hi, stream);
     double v = 0;

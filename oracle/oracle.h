@@ -94,6 +94,8 @@ int orc_render(const orc_scene*, const orc_camera*, int algorithm, uint32_t s_be
 void orc_resolve(const double* sum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb_out);
 
 /* the shared counter-based RNG (documented in DESIGN.md): draw `k` of stream (path_lo,path_hi,stream) */
+/* raw Philox4x32-10 block (checked against the Random123 known-answer vectors in tests) */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_rng_draw(uint64_t seed, uint32_t path_lo, uint32_t path_hi, uint32_t stream, uint32_t k);
 
 #ifdef __cplusplus

@@ -1,0 +1,57 @@
+"""world_size-2 `gloo` test of the N>1 path on CPU: spp-split + one reduce of the f64 framebuffers.
+The per-rank render is stood in for by the oracle (no GPU here); what is under test is the host logic bench.py uses:
+raytracer_amd.dist.spp_range and reduce_framebuffer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd.dist import reduce_framebuffer, spp_range
+
+
+def test_spp_range_partitions_exactly():
+    for world in (1, 2, 3, 4, 8):
+        for spp in (1, 7, 50, 128, 1024):
+            got = [spp_range(r, world, spp) for r in range(world)]
+            covered = [s for b, c in got for s in range(b, b + c)]
+            assert covered == list(range(spp))
+    with pytest.raises(ValueError):
+        spp_range(2, 2, 8)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as O
+    from raytracer_amd import Camera, HittableList
+    w = HittableList.from_json("scenes/simple_hollow_glass.json")
+    osc = O.OracleScene(w.prims(), w.centroids(), w.materials()).build_bvh("sah-position")
+    cam = Camera("scenes/simple_hollow_glass.json", image_width=48, samples_per_pixel=6)
+    b, c = spp_range(rank, world, 6)
+    img, st = osc.render(O.camera_from_rt(cam.c), "bvh", b, c, 50, seed=4)
+    fb = torch.from_numpy(img.copy())
+    reduce_framebuffer(fb, dst=0)
+    rays = torch.tensor([float(st["primary_rays"] + st["scatter_rays"])], dtype=torch.float64)
+    dist.all_reduce(rays)
+    if rank == 0:
+        full, fst = osc.render(O.camera_from_rt(cam.c), "bvh", 0, 6, 50, seed=4)
+        q.put((np.allclose(fb.numpy(), full, rtol=1e-13, atol=0), float(rays.item()) == float(fst["primary_rays"] + fst["scatter_rays"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spp_split_reduce_world_size_2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    same_image, same_rays = q.get()
+    assert same_image and same_rays
