@@ -1,0 +1,50 @@
+"""The reference's own test matrix (src/test.rs: scenes x {naive, bvh-naive, bvh-sah-plane, bvh-sah-position, grid 25/5/1},
+dragon cameras 0..3) re-run as smoke tests through run() of the C++ host — like the reference's tests they assert that the
+run completes, plus the side effects the reference documents: a P3 image and one stats.csv row per run."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+J, P = "native", "ply"
+MATRIX = []
+for scene in ("scenes/simple_fuzzy_metal.json", "scenes/triangle_materials.json", "scenes/weekend-5-80-15.json"):
+    MATRIX += [(scene, J, ["--algorithm", "naive"]), (scene, J, ["-o", "bvh-naive"]), (scene, J, ["-o", "bvh-sah-plane"]),
+               (scene, J, ["-o", "bvh-sah-position"]), (scene, J, ["--algorithm", "grid", "-g", "25"]),
+               (scene, J, ["--algorithm", "grid", "-g", "5"])]
+MATRIX += [("scenes/simple_fuzzy_metal.json", J, ["--algorithm", "grid", "-g", "1"])]
+for scene, fmt in (("scenes/weekend-final.json", J), ("scenes/dragon_recon/dragon_vrip_res4.ply", P)):
+    MATRIX += [(scene, fmt, ["-o", "bvh-naive"]), (scene, fmt, ["-o", "bvh-sah-plane"]), (scene, fmt, ["-o", "bvh-sah-position"]),
+               (scene, fmt, ["--algorithm", "grid", "-g", "25"]), (scene, fmt, ["--algorithm", "grid", "-g", "5"])]
+MATRIX += [("scenes/dragon_recon/dragon_vrip_res4.ply", P, ["--camera", str(c)]) for c in range(4)]
+
+
+@pytest.mark.parametrize("scene,fmt,extra", MATRIX)
+def test_reference_matrix_runs(gpu, tmp_path, scene, fmt, extra):
+    out = str(tmp_path / "output")
+    argv = [scene, "--format", fmt, "--width", "64", "--spp", "2", "--output-dir", out] + extra
+    assert rt.run(argv) == 0
+    ppm = [f for f in os.listdir(out) if f.endswith(".ppm")]
+    assert len(ppm) == 1
+    tok = open(os.path.join(out, ppm[0])).read().split()
+    assert tok[:4] == ["P3", "64", "36", "255"] and len(tok) == 4 + 64 * 36 * 3
+    px = np.array(tok[4:], dtype=int)
+    assert px.min() >= 0 and px.max() <= 255 and px.std() > 0
+    rows = list(csv.DictReader(open(os.path.join(out, "stats.csv"))))
+    assert len(rows) == 1
+    r = rows[0]
+    assert list(r.keys()) == ["seconds", "init_time", "primary_rays", "scatter_rays", "intersection_checks", "traversal_steps",
+                              "overlapping_aabb", "gridbox_intersection_checks", "filename", "primitives", "algorithm", "options",
+                              "image_width", "image_height", "samples_per_pixel", "max_depth"]      # data.rs:6-24
+    assert int(r["primary_rays"]) == 64 * 36 * 2 and r["filename"] == scene and int(r["intersection_checks"]) > 0
+    assert r["algorithm"] in ("Naive", "BVH", "Grid")
+
+
+def test_draw_boxes_is_rejected_loudly(gpu, tmp_path):
+    with pytest.raises(rt.RtError, match="draw-boxes"):
+        rt.run(["scenes/simple_fuzzy_metal.json", "-o", "draw-boxes", "--output-dir", str(tmp_path)])
