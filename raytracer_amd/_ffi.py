@@ -78,7 +78,8 @@ def hip_lib():
     global _hip
     if _hip is not None:
         return _hip
-    lib = C.CDLL(_need(os.path.join(LIB_DIR, "librt_hip.so")), mode=C.RTLD_GLOBAL)
+    # RT_HIP_LIB: diagnostic builds of the same library (e.g. lib/librt_hip_stamps.so); default is the product library
+    lib = C.CDLL(_need(os.environ.get("RT_HIP_LIB") or os.path.join(LIB_DIR, "librt_hip.so")), mode=C.RTLD_GLOBAL)
     P = C.POINTER
     lib.rt_init.argtypes = [C.c_int]; lib.rt_init.restype = C.c_int
     lib.rt_set_profiling.argtypes = [C.c_int]; lib.rt_set_profiling.restype = C.c_int

@@ -27,9 +27,10 @@ int g_device = -1;
 bool g_profiling = false;
 hipStream_t g_stream = nullptr;
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
-uint32_t g_stream_blocks = 2048;
-uint64_t g_batch_paths = 1ull << 24;  // paths in flight per batch
+uint32_t g_stream_blocks = 4096;
+uint64_t g_batch_paths = 0;           // paths in flight per batch; 0 = size from free HBM (RT_BATCH_PATHS overrides)
 uint32_t g_tune = (16u << 16) | (1u << 8) | 2u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
+unsigned long long* g_dbg = nullptr;  // diagnostic builds (-DRT_STAMPS) only
 int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
 
 struct EventPool {
@@ -84,6 +85,7 @@ struct rt_scene {
     // BVH
     bool have_bvh = false; uint32_t n_nodes = 0, bvh_depth = 0;
     DNode* d_nodes = nullptr; DPrim* d_prims_bvh = nullptr; StackEntry* d_stack = nullptr;
+    double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     // grid
     bool have_grid = false; DGrid grid{};
     double* d_cell_aabb = nullptr; uint64_t* d_cell_offset = nullptr; uint32_t* d_prim_list = nullptr;
@@ -129,8 +131,10 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
         if (g_extend_variant == 1)
             hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+        else if (g_extend_variant == 3)
+            hipLaunchKernelGGL(k_extend_bvh3, dim3(g_extend_blocks * (RT_BLOCK / RT_BLOCK3)), dim3(RT_BLOCK3), 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
         else
-            hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats);
+            hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
         break;
     case RT_ALGO_NAIVE:
         hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->n_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
@@ -167,7 +171,19 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
     if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
     if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
 
-    uint32_t k = (uint32_t)(g_batch_paths / WH); if (k < 1) k = 1; if (k > s_count && s_count) k = s_count;
+    // Batch = as many samples per pixel in flight as HBM comfortably holds (196 B of queue state per path): long paths
+    // leave a tail of small, latency-bound launches per batch, so fewer, larger batches are faster (288 GB per GPU).
+    uint64_t batch_paths = g_batch_paths;
+    if (batch_paths == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+        uint64_t have = free_b + sc->ws.cap * 196ull;                     // what this scene's workspace already holds counts as free
+        batch_paths = (uint64_t)((double)have * 0.40 / 196.0);
+        if (batch_paths < (1ull << 22)) batch_paths = 1ull << 22;
+    }
+    uint64_t k64 = batch_paths / WH; if (k64 < 1) k64 = 1; if (s_count && k64 > s_count) k64 = s_count;
+    while (k64 > 1 && WH * k64 > 0xfff00000ull) --k64;                      // path ids are 32-bit
+    uint32_t k = (uint32_t)k64;
     if (WH * k > 0xffffffffull) return fail(RT_E_LIMIT, "batch too large");
     int rc = ensure_workspace(sc, WH * k, max_depth + 2);
     if (rc) return rc;
@@ -190,7 +206,9 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         spans.clear(); g_events.reset();
     };
 
-    const dim3 sgrid(g_stream_blocks), block(RT_BLOCK);
+    const dim3 sgrid(g_stream_blocks), block(RT_SBLOCK);
+    DRootBox rb; memset(&rb, 0, sizeof rb);
+    if (algorithm == RT_ALGO_BVH) { rb.enabled = 1; for (int c = 0; c < 3; ++c) { rb.mn[c] = sc->root_mn[c]; rb.mx[c] = sc->root_mx[c]; } }
     const DPrim* sprims = shade_prims(sc, algorithm);
     bool first = true;
     if (s_count == 0) HIPCHECK(hipMemsetAsync(d_fb, 0, WH * 3 * sizeof(double), st));
@@ -198,7 +216,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         const uint32_t kb = (s_count - s0 < k) ? (s_count - s0) : k;
         HIPCHECK(hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st));
         begin_span(K_GENERATE);
-        hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, s_begin + s0, kb, seed, w.q(0), w.counts);
+        hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, rb, s_begin + s0, kb, seed, w.q(0), w.counts, w.rad, (uint64_t)w.cap, w.stats);
         end_span();
         for (uint32_t b = 0; b < max_depth; ++b) {
             ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.tn = sc->mixed ? w.hit_tn : nullptr; eo.hit = nullptr; eo.trace = 0;
@@ -208,7 +226,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             end_span(); ++extend_launches;
             begin_span(K_SHADE);
             hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
-                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, b, max_depth, seed, w.stats);
+                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint64_t)w.cap, (uint32_t)WH, s_begin + s0, b, max_depth, seed, w.stats);
             end_span();
             HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
@@ -216,7 +234,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             if (*w.h_count == 0) break;
         }
         begin_span(K_RESOLVE);
-        hipLaunchKernelGGL(k_accumulate, sgrid, block, 0, st, w.rad, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
+        hipLaunchKernelGGL(k_accumulate, sgrid, block, 0, st, w.rad, (uint64_t)w.cap, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
         end_span();
         first = false;
     }
@@ -253,9 +271,12 @@ int rt_init(int device) {
         g_device = device;
     }
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
-    if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
+    if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v >= 1 && v <= 3) g_extend_variant = v; }
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
+#ifdef RT_STAMPS
+    if (!g_dbg) { HIPCHECK(hipMalloc(&g_dbg, 16 * sizeof(unsigned long long))); HIPCHECK(hipMemset(g_dbg, 0, 16 * sizeof(unsigned long long))); }
+#endif
     g_inited = true;
     return RT_OK;
 }
@@ -294,6 +315,19 @@ rt_scene* rt_scene_create(const rt_prim* prims, uint32_t n_prims, const rt_mater
 void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
     (void)hipDeviceSynchronize();
+#ifdef RT_STAMPS
+    if (g_dbg) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, g_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[12]) {
+            fprintf(stderr, "[stamps] waves %llu | cycles/wave: loop %.3g refill %.3g internal %.3g leaf %.3g | iterations/wave %.0f (refill %.0f internal %.0f leaf %.0f)\n",
+                    h[12], (double)h[0] / h[12], (double)h[1] / h[12], (double)h[2] / h[12], (double)h[3] / h[12], (double)h[4] / h[12], (double)h[5] / h[12], (double)h[6] / h[12], (double)h[7] / h[12]);
+            fprintf(stderr, "[stamps] cycles per phase call: refill %.0f internal %.0f leaf %.0f | lanes per call: refill %.1f internal %.1f leaf %.1f | live lanes/iteration %.1f\n",
+                    h[5] ? (double)h[1] / h[5] : 0.0, h[6] ? (double)h[2] / h[6] : 0.0, h[7] ? (double)h[3] / h[7] : 0.0,
+                    h[5] ? (double)h[10] / h[5] : 0.0, h[6] ? (double)h[8] / h[6] : 0.0, h[7] ? (double)h[9] / h[7] : 0.0, h[4] ? (double)h[11] / h[4] : 0.0);
+            (void)hipMemset(g_dbg, 0, sizeof h);
+        }
+    }
+#endif
     if (sc->d_prims) (void)hipFree(sc->d_prims); if (sc->d_mats) (void)hipFree(sc->d_mats);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
@@ -324,11 +358,14 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
         }
     }
     for (uint32_t k = 0; k < n; ++k) if (prim_index[k] >= n) return fail(RT_E_ARG, "prim_index[%u] = %u out of range", k, prim_index[k]);
-    std::vector<DNode> dn(n_nodes);
+    // device node i+1 = host node i: children of a node are (2k+1, 2k+2) on the host (bvh.rs:167-168), so shifting by one
+    // puts every sibling pair on a 128-byte boundary (hipMalloc memory is at least 256-byte aligned)
+    std::vector<DNode> dn((size_t)n_nodes + 1);
+    memset(&dn[0], 0, sizeof(DNode));
     for (uint32_t i = 0; i < n_nodes; ++i) {
-        const rt_bvh_node& s = nodes[i]; DNode& d = dn[i];
+        const rt_bvh_node& s = nodes[i]; DNode& d = dn[(size_t)i + 1];
         for (int c = 0; c < 3; ++c) { d.mn[c] = s.min[c]; d.mx[c] = s.max[c]; }
-        if (s.is_leaf) { d.a = s.first; d.b = s.count | RT_LEAF; } else { d.a = s.left; d.b = 0; }
+        if (s.is_leaf) { d.a = s.first; d.b = s.count | RT_LEAF; } else { d.a = s.left + 1; d.b = 0; }
         d.pad0 = d.pad1 = 0;
     }
     std::vector<DPrim> dp(n ? n : 1);
@@ -340,6 +377,7 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     HIPCHECK(hipMalloc(&sc->d_stack, (size_t)depth * g_extend_blocks * RT_BLOCK * sizeof(StackEntry)));
     HIPCHECK(hipMemcpy(sc->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(sc->d_prims_bvh, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    for (int c = 0; c < 3; ++c) { sc->root_mn[c] = nodes[0].min[c]; sc->root_mx[c] = nodes[0].max[c]; }
     sc->n_nodes = n_nodes; sc->bvh_depth = depth; sc->have_bvh = true;
     (void)covered;
     return RT_OK;

@@ -2,7 +2,8 @@
 #pragma once
 #include "rt_device.h"
 
-#define RT_BLOCK 128          // two wave64 per workgroup
+#define RT_BLOCK 128          // extend kernels: two wave64 per workgroup
+#define RT_SBLOCK 256         // streaming kernels (generate, shade, accumulate): block-level queue compaction
 
 // SoA ray queue in HBM: one entry per live path (origin, direction, throughput, path id)
 struct RayQ { double *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb; uint32_t* id; };
@@ -14,6 +15,9 @@ struct ExtendOut { int32_t* prim; double* t; double* tp; double* tn; uint8_t* hi
 // continuation of BvhNode::hit (bvh.rs:210-223): the pending far child and its entry distance
 struct __align__(16) StackEntry { double far_d; uint32_t a, b; };
 
+// root box of the BVH for the early sky test in k_generate (enabled = 0 for naive / grid)
+struct DRootBox { int enabled; double mn[3], mx[3]; };
+
 struct DCamera { uint32_t W, H; V3 center, pixel00, du, dv, ddu, ddv; double defocus_angle; };
 
 struct DGrid {
@@ -23,20 +27,23 @@ struct DGrid {
 
 enum { ST_SCATTER = 0, ST_BOX, ST_PRIM, ST_STEPS, ST_OVERLAP, ST_GRIDBOX, ST_SEGMENTS, ST_N };
 
-__global__ void k_generate(DCamera cam, uint32_t s_base, uint32_t s_count, uint64_t seed, RayQ out, uint32_t* count_out);
+__global__ void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t s_count, uint64_t seed, RayQ out, uint32_t* count_out,
+                           double* rad, uint64_t rad_stride, unsigned long long* stats);
 __global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, const uint32_t* pi, const uint32_t* pj,
                                 uint64_t n, double* orig, double* dir);
 __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                              double tmin0, double tmax0, ExtendOut out, StackEntry* stack, unsigned long long* stats);
 __global__ void k_extend_bvh2(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
-                              double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats);
+                              double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
+__global__ void k_extend_bvh3(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
+                              double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
 __global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                                double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_shade(const DPrim* prims, const DMat* mats, RayQ in, const uint32_t* count_in,
                         const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,
-                        double* rad, uint32_t WH, uint32_t s_base, uint32_t bounce, uint32_t max_depth, uint64_t seed,
+                        double* rad, uint64_t rad_stride, uint32_t WH, uint32_t s_base, uint32_t bounce, uint32_t max_depth, uint64_t seed,
                         unsigned long long* stats);
-__global__ void k_accumulate(const double* rad, uint32_t WH, uint32_t s_count, double* fb, int first_batch);
+__global__ void k_accumulate(const double* rad, uint64_t rad_stride, uint32_t WH, uint32_t s_count, double* fb, int first_batch);
 __global__ void k_load_rays(const double* orig, const double* dir, uint64_t n, RayQ q);

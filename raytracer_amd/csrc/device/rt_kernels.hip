@@ -34,25 +34,54 @@ RT_DEV uint32_t compact_slot(bool alive, uint32_t* counter) {
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// block-level compaction: one atomic per workgroup (a single counter word saturates near 88 atomics/us, so one
+// atomic per wave makes a 10^8-path launch atomic-bound).  Every thread of the block must call it, the same number of times.
+RT_DEV uint32_t block_compact_slot(bool alive, uint32_t* counter, uint32_t* s_tmp /* [blockDim.x/64] */) {
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (lane == 0) s_tmp[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; ++w) total += s_tmp[w];
+        uint32_t base = total ? atomicAdd(counter, total) : 0u;
+        for (uint32_t w = 0; w < n_waves; ++w) { const uint32_t c = s_tmp[w]; s_tmp[w] = base; base += c; }
+    }
+    __syncthreads();
+    return s_tmp[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// camera.rs:182-184
+RT_DEV V3 sky_color(V3 d) {
+    V3 unit_direction = unit(d);
+    double a = 0.5 * (unit_direction.y + 1.0);
+    return (1.0 - a) * v3(1.0, 1.0, 1.0) + a * v3(0.5, 0.7, 1.0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // generate: Camera::get_ray (camera.rs:132-148), sample_square (:189-191), defocus_disk_sample (:145-148).
 // One lane per (pixel, local sample); a wave covers an 8x8 pixel tile so primary rays stay coherent.
 // Path id = s_local * W*H + (j*W + i); RNG path = (j*W+i, s_base + s_local), stream 0.
-__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, uint32_t s_base, uint32_t s_count, uint64_t seed,
-                                                       RayQ out, uint32_t* count_out) {
+// With a BVH the root box test of the first world.hit (hittable_list.rs:84, bvh.rs:182-185) is done here: a primary ray
+// that misses it is a sky pixel sample (camera.rs:182-184) and never enters the queue (its box test is counted here).
+__global__ __launch_bounds__(RT_SBLOCK) void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t s_count, uint64_t seed,
+                                                        RayQ out, uint32_t* count_out, double* __restrict__ rad, uint64_t rad_stride,
+                                                        unsigned long long* stats) {
+    __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
     const uint32_t W = cam.W, H = cam.H;
     const uint32_t tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
-    const uint64_t n_waves = (uint64_t)tiles_x * tiles_y * s_count;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t wave_stride = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t w = wave0; w < n_waves; w += wave_stride) {
-        uint32_t s_local = (uint32_t)(w / ((uint64_t)tiles_x * tiles_y));
-        uint32_t tile = (uint32_t)(w % ((uint64_t)tiles_x * tiles_y));
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y, n_waves = n_tiles * s_count;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = RT_SBLOCK / 64;
+    uint64_t c_culled = 0;
+    for (uint64_t wb = (uint64_t)blockIdx.x * wpb; wb < n_waves; wb += (uint64_t)gridDim.x * wpb) {
+        const uint64_t w = wb + wave;
+        uint32_t s_local = (uint32_t)(w / n_tiles);
+        uint32_t tile = (uint32_t)(w % n_tiles);
         uint32_t i = (tile % tiles_x) * 8 + (lane & 7), j = (tile / tiles_x) * 8 + (lane >> 3);
-        bool valid = i < W && j < H;
+        bool valid = w < n_waves && i < W && j < H;
         V3 orig = v3(0, 0, 0), dir = v3(0, 0, 0);
-        uint32_t pix = j * W + i;
+        const uint32_t pix = j * W + i;
+        const uint32_t id = s_local * (W * H) + pix;
         if (valid) {
             Rng g(seed, pix, s_base + s_local, 0);
             double ox = g.next() - 0.5;
@@ -65,15 +94,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, uint32_t s_b
                 orig = cam.center + (p.x * cam.ddu) + (p.y * cam.ddv);
             }
             dir = pixel_sample - orig;
+            if (root.enabled) {
+                V3 inv = v3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
+                double e0 = 0.001, e1 = __builtin_huge_val();        // camera.rs:161
+                if (!slab(root.mn, root.mx, orig, inv, e0, e1)) {
+                    V3 c = sky_color(dir);                            // throughput is (1,1,1)
+                    rad[id] = c.x; rad[rad_stride + id] = c.y; rad[2 * rad_stride + id] = c.z;
+                    valid = false; ++c_culled;
+                }
+            }
         }
-        uint32_t q = compact_slot(valid, count_out);
+        uint32_t q = block_compact_slot(valid, count_out, s_tmp);
         if (valid) {
             out.ox[q] = orig.x; out.oy[q] = orig.y; out.oz[q] = orig.z;
             out.dx[q] = dir.x; out.dy[q] = dir.y; out.dz[q] = dir.z;
             out.tr[q] = 1.0; out.tg[q] = 1.0; out.tb[q] = 1.0;
-            out.id[q] = s_local * (W * H) + pix;
+            out.id[q] = id;
         }
     }
+    if (stats && root.enabled) { stat_add(stats, ST_BOX, c_culled); stat_add(stats, ST_SEGMENTS, c_culled); }
 }
 
 // parity entry for get_ray: explicit pixel lists, AoS output, no queue
@@ -137,7 +176,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
         HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
         ++c_rays;
 
-        DNode root = nodes[0];
+        DNode root = nodes[1];                       // device node i+1 = host node i (pairs 128-byte aligned)
         double tmax = tmax0;
         ++c_box;
         double e0 = tmin0, e1 = tmax0;
@@ -207,13 +246,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
 //   * the continuation stack's top RT_STK entries live in LDS ([level][lane]: conflict-free for b64 and b32
 //     accesses whatever level each lane is on); deeper entries spill to HBM as stack[level][thread].
 #define RT_STK 8
+// Diagnostic build only (-DRT_STAMPS): per-wave cycle sums per phase of the loop, added into dbg[] at the end.
+// dbg: 0 loop cycles, 1 refill cycles, 2 internal cycles, 3 leaf cycles, 4 iterations, 5 refill iterations, 6 internal
+// iterations, 7 leaf iterations, 8 lanes served by internal phases, 9 lanes served by leaf phases, 10 lanes refilled,
+// 11 live lanes summed over iterations, 12 waves
+#ifdef RT_STAMPS
+#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0; const unsigned long long tk_begin = clock64();
+#define RT_STAMP(x) x
+#else
+#define RT_STAMP_DECL
+#define RT_STAMP(x)
+#endif
 #define RT_REFILL 16
 #define RT_COST_INT 1u    // relative instruction cost of the two phases, for the vote
 #define RT_COST_LEAF 2u
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out,
-                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats) {
+                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
+                                                          unsigned long long* dbg) {
+    RT_STAMP_DECL
     const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu, refill_min = (tune >> 16) & 0xffu;
     __shared__ double s_fd[RT_STK][RT_BLOCK];
     __shared__ uint2 s_ab[RT_STK][RT_BLOCK];
@@ -232,13 +284,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
     double tmax = tmax0;
     HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-    const DNode root = nodes[0];
+    const DNode root = nodes[1];                 // device node i+1 = host node i (pairs 128-byte aligned)
 
     for (;;) {
         // ---- refill idle lanes
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        RT_STAMP(tk0 = clock64(); ++n_it;)
         if (n_idle && !exhausted && (n_idle >= refill_min)) {
+            RT_STAMP(++n_ref;)
             if (c_next >= c_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
@@ -263,6 +317,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
             }
             c_next += (n_idle < avail) ? n_idle : avail;
             all_regular = !__any(active && !regular);    // min/max box test is exact only for regular rays
+            RT_STAMP(l_ref += (n_idle < avail) ? n_idle : avail; tk_ref += clock64() - tk0;)
         }
         if (!__any(active)) { if (exhausted) break; continue; }
 
@@ -272,6 +327,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
         const bool want_leaf = active && (need_pop || (cur_b & RT_LEAF));
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
         const uint32_t n_int = (uint32_t)__popcll(__ballot(active && !want_leaf));
+        RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
         if (n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int)) {   // never starve: one side is non-empty
             // ---- one internal-node visit (bvh.rs:203-229), branch-free apart from the push
             if (active && !want_leaf) {
@@ -299,7 +355,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
                 cur_a = go_right ? R.a : L.a; cur_b = go_right ? R.b : L.b;
                 need_pop = !(lh || rh);
             }
-        } else if (want_leaf) {
+            RT_STAMP(++n_intp; l_int += n_int; tk_int += clock64() - tk0;)
+        } else {
+            if (want_leaf) {
             // ---- leaf tests (bvh.rs:195-202), then pops until the lane has a node again or its ray is finished
             if (!need_pop) {
                 ++c_steps;
@@ -328,8 +386,193 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
                     } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
                 }
             }
+            }
+            RT_STAMP(++n_leafp; l_leaf += n_leaf; tk_leaf += clock64() - tk0;)
         }
     }
+#ifdef RT_STAMPS
+    if (dbg && lane == 0) {
+        const unsigned long long v[13] = {clock64() - tk_begin, tk_ref, tk_int, tk_leaf, n_it, n_ref, n_intp, n_leafp, l_int, l_leaf, l_ref, l_live, 1};
+        for (int i = 0; i < 13; ++i) atomicAdd(&dbg[i], v[i]);
+    }
+#endif
+    if (stats) {
+        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
+        stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
+    }
+}
+
+#define RT_BLOCK3 64
+__global__ __launch_bounds__(RT_BLOCK3) void k_extend_bvh3(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
+                                                          RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+                                                          double tmin0, double tmax0, ExtendOut out,
+                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
+                                                          unsigned long long* dbg) {
+    RT_STAMP_DECL
+    const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu, refill_min = (tune >> 16) & 0xffu;
+    __shared__ double s_fd[RT_STK][RT_BLOCK3];
+    __shared__ uint2 s_ab[RT_STK][RT_BLOCK3];
+    __shared__ __align__(16) char s_stage[RT_BLOCK3 / 64][64 * 128];   // per wave: 64 sibling pairs of 128 B
+    __shared__ uint32_t s_idx[RT_BLOCK3 / 64][64];
+    const uint32_t n = count ? *count : (uint32_t)n_fixed;
+    const uint32_t T = gridDim.x * RT_BLOCK3, tx = threadIdx.x, lane = tx & 63;
+    StackEntry* my_spill = spill + (blockIdx.x * RT_BLOCK3 + tx);
+    uint32_t chunk = n / ((T >> 6) * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
+    uint32_t c_next = 0, c_end = 0;          // wave-uniform: the wave's current chunk of the queue
+    bool exhausted = false;
+    uint32_t c_box = 0, c_prim = 0, c_steps = 0, c_overlap = 0, c_rays = 0;
+
+    bool active = false, need_pop = false, regular = true, all_regular = true;
+    uint32_t q = 0, cur_a = 0, cur_b = 0, sp = 0, lo = 0;
+    bool flag = false;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
+    double tmax = tmax0;
+    HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+    const DNode root = nodes[1];                 // device node i+1 = host node i: sibling pairs are 128-byte aligned
+    char* const stage = s_stage[tx >> 6];
+    uint32_t* const idxq = s_idx[tx >> 6];
+
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        RT_STAMP(tk0 = clock64(); ++n_it;)
+        if (n_idle && !exhausted && (n_idle >= refill_min)) {
+            RT_STAMP(++n_ref;)
+            if (c_next >= c_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) { exhausted = true; c_next = c_end = n; }
+                else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
+            }
+            const uint32_t avail = c_end - c_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < avail) {
+                q = c_next + rank;
+                o = v3(in.ox[q], in.oy[q], in.oz[q]);
+                d = v3(in.dx[q], in.dy[q], in.dz[q]);
+                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                regular = ray_is_regular(o, inv);
+                rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+                ++c_rays; ++c_box;
+                tmax = tmax0; sp = 0; lo = 0; flag = false; need_pop = false;
+                double e0 = tmin0, e1 = tmax0;
+                if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root.a; cur_b = root.b; }   // bvh.rs:84-85
+                else store_hit(out, q, false, rec, prims);
+            }
+            c_next += (n_idle < avail) ? n_idle : avail;
+            all_regular = !__any(active && !regular);    // min/max box test is exact only for regular rays
+            RT_STAMP(l_ref += (n_idle < avail) ? n_idle : avail; tk_ref += clock64() - tk0;)
+        }
+        if (!__any(active)) { if (exhausted) break; continue; }
+
+        // ---- phase vote.  A lane is either on an internal node (wants the two-box visit) or on a leaf / waiting
+        // to pop (wants the primitive tests + stack work).  Running both every iteration leaves most lanes masked
+        // in one of them; instead the wave runs the phase that serves more lanes per instruction and the others wait.
+        const bool want_leaf = active && (need_pop || (cur_b & RT_LEAF));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
+        const uint32_t n_int = (uint32_t)__popcll(__ballot(active && !want_leaf));
+        RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
+        if (n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int)) {   // never starve: one side is non-empty
+            // ---- one internal-node visit (bvh.rs:203-229).  The 128-byte sibling pairs are fetched cooperatively:
+            // lanes that want a visit are ranked, and 8 adjacent lanes pull one pair as one contiguous 128-byte
+            // line straight into LDS (global_load_lds_dwordx4), so the vector memory pipe sees 16 full lines per
+            // instruction instead of 64 lanes x 16 bytes of 64 different lines, and idle lanes cost nothing.
+            // Piece p of rank R sits in slot p ^ (R & 7) of R's 128-byte region (swizzle applied on the source side).
+            const bool want_int = active && !want_leaf;
+            const unsigned long long m_int = __ballot(want_int);
+            const uint32_t rnk = (uint32_t)__popcll(m_int & ((1ull << lane) - 1ull));
+            if (want_int) idxq[rnk] = cur_a;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_grp = (n_int + 7u) >> 3;
+            for (uint32_t kk = 0; kk < n_grp; ++kk) {
+                const uint32_t R = kk * 8u + (lane >> 3);
+                if (R < n_int) {
+                    const uint32_t piece = (lane & 7u) ^ (R & 7u);
+                    const char* src = (const char*)(nodes + idxq[R]) + piece * 16u;
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                     (void __attribute__((address_space(3)))*)(stage + kk * 1024u), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (want_int) {
+                ++c_steps;                               // bvh.rs:190
+                DNode L, R;
+                {
+                    const char* reg = stage + rnk * 128u; const uint32_t sw = rnk & 7u;
+                    uint4 q[8];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i) q[i] = *(const uint4*)(reg + ((i ^ sw) * 16u));
+                    const double* dq = (const double*)q;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { L.mn[i] = dq[i]; L.mx[i] = dq[3 + i]; R.mn[i] = dq[8 + i]; R.mx[i] = dq[11 + i]; }
+                    L.a = q[3].x; L.b = q[3].y; R.a = q[7].x; R.b = q[7].y;
+                }
+                c_box += 2;
+                double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
+                bool lh, rh;
+                if (all_regular) { lh = slab_fast(L.mn, L.mx, o, inv, ld, lx); rh = slab_fast(R.mn, R.mx, o, inv, rd, rx); }
+                else { lh = slab(L.mn, L.mx, o, inv, ld, lx); rh = slab(R.mn, R.mx, o, inv, rd, rx); }
+                const bool both = lh && rh;
+                const bool go_right = both ? (ld >= rd) : rh;      // bvh.rs:210-211 (tie -> right is `close`), :226-227
+                if (both) {
+                    if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
+                        StackEntry e; const uint32_t s = lo & (RT_STK - 1);
+                        e.far_d = s_fd[s][tx]; e.a = s_ab[s][tx].x; e.b = s_ab[s][tx].y;
+                        my_spill[(uint64_t)lo * T] = e; ++lo;
+                    }
+                    const uint32_t s = sp & (RT_STK - 1);
+                    s_fd[s][tx] = fmax(ld, rd);          // bvh.rs:212
+                    s_ab[s][tx] = make_uint2(go_right ? L.a : R.a, (go_right ? L.b : R.b) | (flag ? 0x40000000u : 0u));
+                    ++sp; flag = false;
+                }
+                cur_a = go_right ? R.a : L.a; cur_b = go_right ? R.b : L.b;
+                need_pop = !(lh || rh);
+            }
+            RT_STAMP(++n_intp; l_int += n_int; tk_int += clock64() - tk0;)
+        } else {
+            if (want_leaf) {
+            // ---- leaf tests (bvh.rs:195-202), then pops until the lane has a node again or its ray is finished
+            if (!need_pop) {
+                ++c_steps;
+                const uint32_t first = cur_a, cnt = cur_b & 0x3fffffffu;
+                double closest = tmax;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    ++c_prim;
+                    const DPrim P = prims[first + k];
+                    if (hit_prim(P, (int32_t)(first + k), o, d, tmin0, closest, rec)) { flag = true; closest = rec.t; }
+                }
+                need_pop = true;
+            }
+            while (need_pop) {
+                if (sp == 0) {
+                    store_hit(out, q, rec.prim >= 0, rec, prims);
+                    active = false; need_pop = false;
+                } else {
+                    --sp;
+                    double far_d; uint32_t ea, eb;
+                    if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ea = e.a; eb = e.b; }
+                    else { const uint32_t s = sp & (RT_STK - 1); far_d = s_fd[s][tx]; ea = s_ab[s][tx].x; eb = s_ab[s][tx].y; }
+                    const bool close_hit = flag;
+                    flag = flag | ((eb >> 30) & 1u);
+                    if (close_hit) {                     // bvh.rs:213-222
+                        if (far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }
+                    } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
+                }
+            }
+            }
+            RT_STAMP(++n_leafp; l_leaf += n_leaf; tk_leaf += clock64() - tk0;)
+        }
+    }
+#ifdef RT_STAMPS
+    if (dbg && lane == 0) {
+        const unsigned long long v[13] = {clock64() - tk_begin, tk_ref, tk_int, tk_leaf, n_it, n_ref, n_intp, n_leafp, l_int, l_leaf, l_ref, l_live, 1};
+        for (int i = 0; i < 13; ++i) atomicAdd(&dbg[i], v[i]);
+    }
+#endif
     if (stats) {
         stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
         stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
@@ -489,20 +732,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
 // normal and front_face as sphere.rs:51-52 / triangle.rs:39-41,77 compute them.
 // The throughput is a left-to-right product where the reference nests right-to-left (camera.rs:172):
 // radiance may differ from the reference's in the last ulps; hit/miss decisions are unaffected.
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
+__global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
                                                     RayQ in, const uint32_t* __restrict__ count_in,
                                                     const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
-                                                    double* __restrict__ rad, uint32_t WH, uint32_t s_base,
+                                                    double* __restrict__ rad, uint64_t rad_stride, uint32_t WH, uint32_t s_base,
                                                     uint32_t bounce, uint32_t max_depth, uint64_t seed,
                                                     unsigned long long* stats) {
+    __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
     const uint64_t n = (uint64_t)*count_in;
-    const uint32_t T = gridDim.x * RT_BLOCK;
-    const uint32_t tid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t T = (uint64_t)gridDim.x * RT_SBLOCK;
     uint64_t c_scatter = 0;
-    for (uint64_t base = tid - lane; base < n; base += T) {
-        const uint64_t q = base + lane;
+    for (uint64_t base = (uint64_t)blockIdx.x * RT_SBLOCK; base < n; base += T) {      // uniform per block (barriers inside)
+        const uint64_t q = base + threadIdx.x;
         const bool valid = q < n;
         bool alive = false;
         V3 no = v3(0, 0, 0), nd = v3(0, 0, 0), thr = v3(0, 0, 0);
@@ -515,10 +757,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ pr
             int32_t pi = hit_prim_[q];
             V3 radiance = v3(0, 0, 0);
             if (pi < 0) {                                             // camera.rs:182-184
-                V3 unit_direction = unit(d);
-                double a = 0.5 * (unit_direction.y + 1.0);
-                V3 sky = (1.0 - a) * v3(1.0, 1.0, 1.0) + a * v3(0.5, 0.7, 1.0);
-                radiance = thr * sky;
+                radiance = thr * sky_color(d);
             } else {
                 DPrim P = prims[pi];
                 double tp = hit_tp[q];
@@ -563,10 +802,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ pr
                 }
             }
             if (!alive) {                                             // every path writes its slot exactly once
-                rad[(uint64_t)id * 3] = radiance.x; rad[(uint64_t)id * 3 + 1] = radiance.y; rad[(uint64_t)id * 3 + 2] = radiance.z;
+                rad[id] = radiance.x; rad[rad_stride + id] = radiance.y; rad[2 * rad_stride + id] = radiance.z;
             }
         }
-        uint32_t w = compact_slot(alive, count_out);
+        uint32_t w = block_compact_slot(alive, count_out, s_tmp);
         if (alive) {
             out.ox[w] = no.x; out.oy[w] = no.y; out.oz[w] = no.z;
             out.dx[w] = nd.x; out.dy[w] = nd.y; out.dz[w] = nd.z;
@@ -578,14 +817,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DPrim* __restrict__ pr
 }
 
 // resolve: `pixel_color += ray_color(...)` (camera.rs:72) for the batch's samples, in sample order.
-__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const double* __restrict__ rad, uint32_t WH, uint32_t s_count,
-                                                         double* __restrict__ fb, int first_batch) {
-    uint64_t e = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;     // element of the W*H*3 framebuffer
-    const uint64_t N = (uint64_t)WH * 3;
-    for (; e < N; e += (uint64_t)gridDim.x * RT_BLOCK) {
-        double acc = first_batch ? 0.0 : fb[e];
-        for (uint32_t s = 0; s < s_count; ++s) acc = acc + rad[(uint64_t)s * N + e];
-        fb[e] = acc;
+__global__ __launch_bounds__(RT_SBLOCK) void k_accumulate(const double* __restrict__ rad, uint64_t rad_stride, uint32_t WH, uint32_t s_count,
+                                                          double* __restrict__ fb, int first_batch) {
+    for (uint64_t p = (uint64_t)blockIdx.x * RT_SBLOCK + threadIdx.x; p < WH; p += (uint64_t)gridDim.x * RT_SBLOCK) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = first_batch ? 0.0 : fb[p * 3 + c];
+            const double* plane = rad + (uint64_t)c * rad_stride + p;
+            for (uint32_t s = 0; s < s_count; ++s) acc = acc + plane[(uint64_t)s * WH];
+            fb[p * 3 + c] = acc;
+        }
     }
 }
 
