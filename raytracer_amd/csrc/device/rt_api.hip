@@ -131,8 +131,6 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
         if (g_extend_variant == 1)
             hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
-        else if (g_extend_variant == 3)
-            hipLaunchKernelGGL(k_extend_bvh3, dim3(g_extend_blocks * (RT_BLOCK / RT_BLOCK3)), dim3(RT_BLOCK3), 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
         else
             hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
         break;
@@ -271,7 +269,7 @@ int rt_init(int device) {
         g_device = device;
     }
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
-    if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v >= 1 && v <= 3) g_extend_variant = v; }
+    if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
 #ifdef RT_STAMPS
@@ -286,7 +284,7 @@ int rt_set_profiling(int on) { g_profiling = on != 0; return RT_OK; }
 rt_scene* rt_scene_create(const rt_prim* prims, uint32_t n_prims, const rt_material* mats, uint32_t n_mats) {
     if (!g_inited) { fail(RT_E_STATE, "rt_init() has not been called"); return nullptr; }
     if ((n_prims && !prims) || (n_mats && !mats)) { fail(RT_E_ARG, "null array"); return nullptr; }
-    if (n_prims > 0x3fffffffu) { fail(RT_E_LIMIT, "more than 2^30 primitives"); return nullptr; }
+    if (n_prims > 0x1fffffffu) { fail(RT_E_LIMIT, "more than 2^29 primitives"); return nullptr; }
     for (uint32_t i = 0; i < n_prims; ++i) {
         if (prims[i].type > RT_TRIANGLE) { fail(RT_E_ARG, "primitive %u has unknown type %u", i, prims[i].type); return nullptr; }
         if (prims[i].material >= n_mats) { fail(RT_E_ARG, "primitive %u names material %u of %u", i, prims[i].material, n_mats); return nullptr; }

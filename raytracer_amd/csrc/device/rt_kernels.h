@@ -35,8 +35,6 @@ __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, co
                              double tmin0, double tmax0, ExtendOut out, StackEntry* stack, unsigned long long* stats);
 __global__ void k_extend_bvh2(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
-__global__ void k_extend_bvh3(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
-                              double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
 __global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                                double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,

@@ -246,6 +246,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
 //   * the continuation stack's top RT_STK entries live in LDS ([level][lane]: conflict-free for b64 and b32
 //     accesses whatever level each lane is on); deeper entries spill to HBM as stack[level][thread].
 #define RT_STK 8
+#define RT_LEAF_STARTED 0x20000000u   // cur_b of a leaf being processed: bit 29 = its traversal step has been counted
+#define RT_LEAF_COUNT 0x1fffffffu     //                                      bits 0..28 = primitives still to test
 // Diagnostic build only (-DRT_STAMPS): per-wave cycle sums per phase of the loop, added into dbg[] at the end.
 // dbg: 0 loop cycles, 1 refill cycles, 2 internal cycles, 3 leaf cycles, 4 iterations, 5 refill iterations, 6 internal
 // iterations, 7 leaf iterations, 8 lanes served by internal phases, 9 lanes served by leaf phases, 10 lanes refilled,
@@ -359,193 +361,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
         } else {
             if (want_leaf) {
             // ---- leaf tests (bvh.rs:195-202), then pops until the lane has a node again or its ray is finished
+            // one primitive per call: 96 % of the leaves hold one primitive, and a lane that has more keeps its place
+            // (cur_a / count in cur_b advance) and joins the next leaf phase, instead of making the whole wave loop.
+            // closest_so_far of the leaf (bvh.rs:193,200) lives in tmax: once a primitive is accepted the frame's old
+            // tmax is dead (every later entry into a node goes through a pop with close_hit set, which reloads it).
             if (!need_pop) {
-                ++c_steps;
-                const uint32_t first = cur_a, cnt = cur_b & 0x3fffffffu;
-                double closest = tmax;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    ++c_prim;
-                    const DPrim P = prims[first + k];
-                    if (hit_prim(P, (int32_t)(first + k), o, d, tmin0, closest, rec)) { flag = true; closest = rec.t; }
-                }
-                need_pop = true;
-            }
-            while (need_pop) {
-                if (sp == 0) {
-                    store_hit(out, q, rec.prim >= 0, rec, prims);
-                    active = false; need_pop = false;
-                } else {
-                    --sp;
-                    double far_d; uint32_t ea, eb;
-                    if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ea = e.a; eb = e.b; }
-                    else { const uint32_t s = sp & (RT_STK - 1); far_d = s_fd[s][tx]; ea = s_ab[s][tx].x; eb = s_ab[s][tx].y; }
-                    const bool close_hit = flag;
-                    flag = flag | ((eb >> 30) & 1u);
-                    if (close_hit) {                     // bvh.rs:213-222
-                        if (far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }
-                    } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
-                }
-            }
-            }
-            RT_STAMP(++n_leafp; l_leaf += n_leaf; tk_leaf += clock64() - tk0;)
-        }
-    }
-#ifdef RT_STAMPS
-    if (dbg && lane == 0) {
-        const unsigned long long v[13] = {clock64() - tk_begin, tk_ref, tk_int, tk_leaf, n_it, n_ref, n_intp, n_leafp, l_int, l_leaf, l_ref, l_live, 1};
-        for (int i = 0; i < 13; ++i) atomicAdd(&dbg[i], v[i]);
-    }
-#endif
-    if (stats) {
-        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
-        stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
-    }
-}
-
-#define RT_BLOCK3 64
-__global__ __launch_bounds__(RT_BLOCK3) void k_extend_bvh3(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
-                                                          RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
-                                                          double tmin0, double tmax0, ExtendOut out,
-                                                          StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
-                                                          unsigned long long* dbg) {
-    RT_STAMP_DECL
-    const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu, refill_min = (tune >> 16) & 0xffu;
-    __shared__ double s_fd[RT_STK][RT_BLOCK3];
-    __shared__ uint2 s_ab[RT_STK][RT_BLOCK3];
-    __shared__ __align__(16) char s_stage[RT_BLOCK3 / 64][64 * 128];   // per wave: 64 sibling pairs of 128 B
-    __shared__ uint32_t s_idx[RT_BLOCK3 / 64][64];
-    const uint32_t n = count ? *count : (uint32_t)n_fixed;
-    const uint32_t T = gridDim.x * RT_BLOCK3, tx = threadIdx.x, lane = tx & 63;
-    StackEntry* my_spill = spill + (blockIdx.x * RT_BLOCK3 + tx);
-    uint32_t chunk = n / ((T >> 6) * 4u);
-    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
-    uint32_t c_next = 0, c_end = 0;          // wave-uniform: the wave's current chunk of the queue
-    bool exhausted = false;
-    uint32_t c_box = 0, c_prim = 0, c_steps = 0, c_overlap = 0, c_rays = 0;
-
-    bool active = false, need_pop = false, regular = true, all_regular = true;
-    uint32_t q = 0, cur_a = 0, cur_b = 0, sp = 0, lo = 0;
-    bool flag = false;
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
-    double tmax = tmax0;
-    HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-    const DNode root = nodes[1];                 // device node i+1 = host node i: sibling pairs are 128-byte aligned
-    char* const stage = s_stage[tx >> 6];
-    uint32_t* const idxq = s_idx[tx >> 6];
-
-    for (;;) {
-        // ---- refill idle lanes
-        const unsigned long long idle = __ballot(!active);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        RT_STAMP(tk0 = clock64(); ++n_it;)
-        if (n_idle && !exhausted && (n_idle >= refill_min)) {
-            RT_STAMP(++n_ref;)
-            if (c_next >= c_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) { exhausted = true; c_next = c_end = n; }
-                else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
-            }
-            const uint32_t avail = c_end - c_next;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && rank < avail) {
-                q = c_next + rank;
-                o = v3(in.ox[q], in.oy[q], in.oz[q]);
-                d = v3(in.dx[q], in.dy[q], in.dz[q]);
-                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                regular = ray_is_regular(o, inv);
-                rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-                ++c_rays; ++c_box;
-                tmax = tmax0; sp = 0; lo = 0; flag = false; need_pop = false;
-                double e0 = tmin0, e1 = tmax0;
-                if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root.a; cur_b = root.b; }   // bvh.rs:84-85
-                else store_hit(out, q, false, rec, prims);
-            }
-            c_next += (n_idle < avail) ? n_idle : avail;
-            all_regular = !__any(active && !regular);    // min/max box test is exact only for regular rays
-            RT_STAMP(l_ref += (n_idle < avail) ? n_idle : avail; tk_ref += clock64() - tk0;)
-        }
-        if (!__any(active)) { if (exhausted) break; continue; }
-
-        // ---- phase vote.  A lane is either on an internal node (wants the two-box visit) or on a leaf / waiting
-        // to pop (wants the primitive tests + stack work).  Running both every iteration leaves most lanes masked
-        // in one of them; instead the wave runs the phase that serves more lanes per instruction and the others wait.
-        const bool want_leaf = active && (need_pop || (cur_b & RT_LEAF));
-        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
-        const uint32_t n_int = (uint32_t)__popcll(__ballot(active && !want_leaf));
-        RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
-        if (n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int)) {   // never starve: one side is non-empty
-            // ---- one internal-node visit (bvh.rs:203-229).  The 128-byte sibling pairs are fetched cooperatively:
-            // lanes that want a visit are ranked, and 8 adjacent lanes pull one pair as one contiguous 128-byte
-            // line straight into LDS (global_load_lds_dwordx4), so the vector memory pipe sees 16 full lines per
-            // instruction instead of 64 lanes x 16 bytes of 64 different lines, and idle lanes cost nothing.
-            // Piece p of rank R sits in slot p ^ (R & 7) of R's 128-byte region (swizzle applied on the source side).
-            const bool want_int = active && !want_leaf;
-            const unsigned long long m_int = __ballot(want_int);
-            const uint32_t rnk = (uint32_t)__popcll(m_int & ((1ull << lane) - 1ull));
-            if (want_int) idxq[rnk] = cur_a;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t n_grp = (n_int + 7u) >> 3;
-            for (uint32_t kk = 0; kk < n_grp; ++kk) {
-                const uint32_t R = kk * 8u + (lane >> 3);
-                if (R < n_int) {
-                    const uint32_t piece = (lane & 7u) ^ (R & 7u);
-                    const char* src = (const char*)(nodes + idxq[R]) + piece * 16u;
-                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                                     (void __attribute__((address_space(3)))*)(stage + kk * 1024u), 16, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (want_int) {
-                ++c_steps;                               // bvh.rs:190
-                DNode L, R;
-                {
-                    const char* reg = stage + rnk * 128u; const uint32_t sw = rnk & 7u;
-                    uint4 q[8];
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i) q[i] = *(const uint4*)(reg + ((i ^ sw) * 16u));
-                    const double* dq = (const double*)q;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { L.mn[i] = dq[i]; L.mx[i] = dq[3 + i]; R.mn[i] = dq[8 + i]; R.mx[i] = dq[11 + i]; }
-                    L.a = q[3].x; L.b = q[3].y; R.a = q[7].x; R.b = q[7].y;
-                }
-                c_box += 2;
-                double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
-                bool lh, rh;
-                if (all_regular) { lh = slab_fast(L.mn, L.mx, o, inv, ld, lx); rh = slab_fast(R.mn, R.mx, o, inv, rd, rx); }
-                else { lh = slab(L.mn, L.mx, o, inv, ld, lx); rh = slab(R.mn, R.mx, o, inv, rd, rx); }
-                const bool both = lh && rh;
-                const bool go_right = both ? (ld >= rd) : rh;      // bvh.rs:210-211 (tie -> right is `close`), :226-227
-                if (both) {
-                    if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
-                        StackEntry e; const uint32_t s = lo & (RT_STK - 1);
-                        e.far_d = s_fd[s][tx]; e.a = s_ab[s][tx].x; e.b = s_ab[s][tx].y;
-                        my_spill[(uint64_t)lo * T] = e; ++lo;
-                    }
-                    const uint32_t s = sp & (RT_STK - 1);
-                    s_fd[s][tx] = fmax(ld, rd);          // bvh.rs:212
-                    s_ab[s][tx] = make_uint2(go_right ? L.a : R.a, (go_right ? L.b : R.b) | (flag ? 0x40000000u : 0u));
-                    ++sp; flag = false;
-                }
-                cur_a = go_right ? R.a : L.a; cur_b = go_right ? R.b : L.b;
-                need_pop = !(lh || rh);
-            }
-            RT_STAMP(++n_intp; l_int += n_int; tk_int += clock64() - tk0;)
-        } else {
-            if (want_leaf) {
-            // ---- leaf tests (bvh.rs:195-202), then pops until the lane has a node again or its ray is finished
-            if (!need_pop) {
-                ++c_steps;
-                const uint32_t first = cur_a, cnt = cur_b & 0x3fffffffu;
-                double closest = tmax;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    ++c_prim;
-                    const DPrim P = prims[first + k];
-                    if (hit_prim(P, (int32_t)(first + k), o, d, tmin0, closest, rec)) { flag = true; closest = rec.t; }
-                }
-                need_pop = true;
+                if (!(cur_b & RT_LEAF_STARTED)) { ++c_steps; cur_b |= RT_LEAF_STARTED; }   // bvh.rs:190, once per leaf
+                ++c_prim;
+                const DPrim P = prims[cur_a];
+                if (hit_prim(P, (int32_t)cur_a, o, d, tmin0, tmax, rec)) { flag = true; tmax = rec.t; }
+                ++cur_a; --cur_b;
+                need_pop = (cur_b & RT_LEAF_COUNT) == 0;
             }
             while (need_pop) {
                 if (sp == 0) {

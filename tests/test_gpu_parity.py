@@ -191,3 +191,20 @@ def test_errors_are_reported_not_crashed(gpu):
         w.hit(np.zeros((1, 3)), np.ones((1, 3)), algorithm="grid")
     assert w.hit(np.zeros((0, 3)), np.zeros((0, 3)), algorithm="naive")["prim"].shape == (0,)
     w.close()
+
+
+def test_reference_form_extend_kernel_agrees(gpu, monkeypatch):
+    """RT_EXTEND_VARIANT=1 selects the plain one-ray-per-thread extend kernel (kept for A/B runs): same bits."""
+    import raytracer_amd as rt
+    w = load_world("dragon_res4")
+    osc = setup_pair(w, "bvh", "sah-plane")
+    w.upload()
+    ro, rd = random_rays(30000, 5, -15.0, 25.0)
+    ref = osc.trace("bvh", ro, rd)
+    try:
+        monkeypatch.setenv("RT_EXTEND_VARIANT", "1"); rt.init(0)
+        assert_trace_equal(w.hit(ro, rd), ref, "variant 1")
+    finally:
+        monkeypatch.setenv("RT_EXTEND_VARIANT", "2"); rt.init(0)
+    assert_trace_equal(w.hit(ro, rd), ref, "variant 2")
+    w.close()
