@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_res3", "dragon_res4", "weekend-final", "weekend-mixed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsing N>1 on a one-GPU box")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline duration")
     return ap.parse_args()
 
@@ -64,10 +66,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if a.force_device >= 0:
+        local_rank = a.force_device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     import raytracer_amd as rt
     from raytracer_amd import Camera
@@ -137,8 +144,8 @@ def main():
                        "init_seconds_excluded": round(init_s, 2)},
             "rays_per_step": total_rays / a.steps,
             "kernel_ms_per_step": {k: agg[k] / a.steps for k in ("generate_ms", "extend_ms", "shade_ms", "resolve_ms")},
-            "roofline": {"kernel": "k_extend_bvh", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"kernel": "k_extend_bvh2", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": measured_traffic(seg / launches),
                          "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": agg["extend_ms"] / launches,
                          "launches": launches, "bytes_per_segment": alg_bytes / max(seg, 1),
                          "box_tests_per_segment": nbox / max(seg, 1), "prim_tests_per_segment": nprim / max(seg, 1)},
@@ -150,6 +157,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(segments_per_launch):
+    """HBM-side bytes per extend launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE per ray segment,
+    profiles/round1_traffic.json) scaled to this run's segments per launch; None when the file is absent."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
+        return (t["fetch_bytes_per_segment_corrected_x2"] + t["write_bytes_per_segment"]) * segments_per_launch
+    except Exception:
+        return None
 
 
 def cpu_baseline(w, cam_name, a):
