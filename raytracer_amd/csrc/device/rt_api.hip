@@ -180,7 +180,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         if (batch_paths < (1ull << 22)) batch_paths = 1ull << 22;
     }
     uint64_t k64 = batch_paths / WH; if (k64 < 1) k64 = 1; if (s_count && k64 > s_count) k64 = s_count;
-    while (k64 > 1 && WH * k64 > 0xfff00000ull) --k64;                      // path ids are 32-bit
+    while (k64 > 1 && WH * k64 > 0xf0000000ull) --k64;                      // path ids and the extend fetch counter are 32-bit (headroom for one chunk per wave)
     uint32_t k = (uint32_t)k64;
     if (WH * k > 0xffffffffull) return fail(RT_E_LIMIT, "batch too large");
     int rc = ensure_workspace(sc, WH * k, max_depth + 2);
