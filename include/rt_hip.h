@@ -91,10 +91,19 @@ int rt_scene_set_bvh(rt_scene*, const rt_bvh_node* nodes, uint32_t n_nodes, cons
  * CSR offsets (n_cells + 1) and the concatenated GridBox.objects lists (file-order indices). */
 int rt_scene_set_grid(rt_scene*, const rt_grid_desc*, const double* cell_aabb, const uint64_t* cell_offset, const uint32_t* prim_list);
 
+/* Replaces HittableList.options (hittable_list.rs:20, Options rtweekend.rs:88-93) for the one option that acts on the
+ * hot path: RT_OPT_DRAW_BOXES = `-o draw-boxes` (rtweekend.rs:92,128,146).  When set, every successful AABB test whose
+ * entry point lies on a box edge marks the ray (aabb.rs:57-60,90-97) and ray_color returns red for it
+ * (camera.rs:162-164,178-180); rt_trace reports the mark as bit 1 of out_hit.  The BVH build options are consumed by
+ * the host builder and never reach the device. */
+enum { RT_OPT_DRAW_BOXES = 1 };
+int rt_scene_set_options(rt_scene*, uint32_t flags);
+
 /* Parity entry: one `HittableList::hit(r, Interval(tmin,tmax), &mut HitRecord::default(), data)`
  * (hittable_list.rs:65-102) per ray.  orig/dir are n*3 doubles (xyz interleaved).  Any output may be NULL.
  * out_prim: file-order index of the last accepted primitive (-1: none); out_t: rec.t after the call;
- * out_tp: the t at which rec.p was last written (rec.p == orig + out_tp*dir); out_hit: the return value. */
+ * out_tp: the t at which rec.p was last written (rec.p == orig + out_tp*dir); out_hit: bit 0 = the return value,
+ * bit 1 = rec.hits_aabb_edge (hittable.rs:20; only ever set under RT_OPT_DRAW_BOXES). */
 int rt_trace(rt_scene*, int algorithm, const double* orig, const double* dir, uint64_t n, double tmin, double tmax,
              int32_t* out_prim, double* out_t, double* out_tp, uint8_t* out_hit, rt_stats* stats);
 

@@ -113,7 +113,8 @@ struct HitRecord {
     /* bookkeeping that is not in the reference: which object was accepted last, and the t at which
      * rec.p was last written (rec.p == at(tp) bit-for-bit whenever prim >= 0 or a triangle reached :59) */
     int32_t prim; double tp;
-    HitRecord() : p(v3(0, 0, 0)), normal(v3(0, 0, 0)), mat(-1), t(0.0), front_face(false), prim(-1), tp(0.0) {}
+    bool hits_aabb_edge;                                                                       /* hittable.rs:20 */
+    HitRecord() : p(v3(0, 0, 0)), normal(v3(0, 0, 0)), mat(-1), t(0.0), front_face(false), prim(-1), tp(0.0), hits_aabb_edge(false) {}
 };
 inline void set_face_normal(HitRecord& rec, const Ray& r, V3 outward) {                        /* hittable.rs:26-29 */
     rec.front_face = dot(r.dir, outward) < 0.0;
@@ -124,8 +125,16 @@ inline void set_face_normal(HitRecord& rec, const Ray& r, V3 outward) {         
 struct AABB { V3 min, max; };                                                                  /* :12-15 (Default = zeros) */
 inline AABB aabb_default() { AABB b = {v3(0, 0, 0), v3(0, 0, 0)}; return b; }
 struct Exit { uint32_t axis; int direction; };                                                 /* :149-153 */
-/* :28-62 without the draw_boxes branch (:57-60, out of scope).  Returns false for None. */
-inline bool aabb_hit(const AABB& b, const Ray& ray, Interval ray_t, Interval& out_t, Exit& exit_) {
+inline bool aabb_is_edge(const AABB& b, V3 point) {                                            /* :90-97 */
+    int count = 0;
+    for (unsigned axis = 0; axis < 3; ++axis) {
+        double p = idx(point, axis), mn = idx(b.min, axis), mx = idx(b.max, axis);
+        if ((p <= mn + 0.01 && p >= mn - 0.01) || (p <= mx + 0.01 && p >= mx - 0.01)) ++count;
+    }
+    return count >= 2;
+}
+/* :28-62.  Returns false for None.  `draw_boxes` is Options.draw_boxes (rtweekend.rs:92): sticky edge flag on rec (:57-60). */
+inline bool aabb_hit(const AABB& b, const Ray& ray, Interval ray_t, Interval& out_t, Exit& exit_, HitRecord& rec, bool draw_boxes) {
     exit_.axis = 0; exit_.direction = 0;
     for (unsigned axis = 0; axis < 3; ++axis) {
         double amin = idx(b.min, axis), amax = idx(b.max, axis);
@@ -141,6 +150,8 @@ inline bool aabb_hit(const AABB& b, const Ray& ray, Interval ray_t, Interval& ou
         }
         if (ray_t.max < ray_t.min) return false;
     }
+    V3 hit_point = ray.orig + ray_t.min * ray.dir;                                            /* :57 */
+    if (draw_boxes && aabb_is_edge(b, hit_point)) rec.hits_aabb_edge = true;
     out_t = ray_t;
     return true;
 }
@@ -211,7 +222,8 @@ struct orc_scene {
     /* Grid (grid.rs:11-18) */
     bool have_grid;
     std::vector<GridBox> boxes; V3 box_size, origin, total_size; AABB grid_aabb;
-    orc_scene() : have_bvh(false), bvh_mode(0), node_pointer(0), have_grid(false) {}
+    bool draw_boxes;                          /* Options.draw_boxes rtweekend.rs:92,128 */
+    orc_scene() : have_bvh(false), bvh_mode(0), node_pointer(0), have_grid(false), draw_boxes(false) {}
 };
 
 namespace {
@@ -361,10 +373,10 @@ struct Trace {
     const orc_scene& sc; Counters& data;
     Trace(const orc_scene& s, Counters& d) : sc(s), data(d) {}
 
-    bool node_hit_aabb(const BvhNode& n, const Ray& r, Interval ray_t, double& dist) { /* bvh.rs:182-185 */
+    bool node_hit_aabb(const BvhNode& n, const Ray& r, Interval ray_t, HitRecord& rec, double& dist) { /* bvh.rs:182-185 */
         data.intersection_checks++; data.box_tests++;
         Interval t; Exit e;
-        if (!aabb_hit(n.aabb, r, ray_t, t, e)) return false;
+        if (!aabb_hit(n.aabb, r, ray_t, t, e, rec, sc.draw_boxes)) return false;
         dist = t.min;
         return true;
     }
@@ -381,9 +393,9 @@ struct Trace {
         } else {
             const BvhNode& left = sc.nodes[n.left];
             double ld = 0, rd = 0;
-            bool lh = node_hit_aabb(left, r, ray_t, ld);
+            bool lh = node_hit_aabb(left, r, ray_t, rec, ld);
             const BvhNode& right = sc.nodes[n.right];
-            bool rh = node_hit_aabb(right, r, ray_t, rd);
+            bool rh = node_hit_aabb(right, r, ray_t, rec, rd);
             if (lh && rh) {
                 const BvhNode& close = (ld >= rd) ? right : left;
                 const BvhNode& far_ = (ld >= rd) ? left : right;
@@ -463,7 +475,7 @@ struct Trace {
             if (depth > (uint32_t)sat_i32(sc.total_size.z)) return false;   /* `as u32` of 200.0 */
             data.traversal_steps++;
             Interval universe = {-INF, INF}, t_hit; Exit ex;
-            if (!aabb_hit(gb->aabb, ray, universe, t_hit, ex)) return false;
+            if (!aabb_hit(gb->aabb, ray, universe, t_hit, ex, rec, sc.draw_boxes)) return false;   /* grid.rs:155 */
             V3 step = v3(0, 0, 0);                              /* aabb.rs:161-165 */
             set_idx(step, ex.axis, (double)ex.direction * idx(sc.box_size, ex.axis));
             HitRecord rec_copy = rec;
@@ -495,7 +507,7 @@ struct Trace {
         } else if (algorithm == ORC_ALGO_BVH) {
             const BvhNode& root = sc.nodes[0];
             double d;
-            bool root_hit = node_hit_aabb(root, r, ray_t, d);
+            bool root_hit = node_hit_aabb(root, r, ray_t, rec, d);
             return root_hit && node_hit(root, r, ray_t, rec);
         } else {
             const GridBox* initial = get_box_enter(r);          /* grid.rs:139-147 */
@@ -542,12 +554,13 @@ struct Trace {
         return r0 + (1.0 - r0) * (x * x4);
     }
 
-    /* ray_color camera.rs:153-186 (draw_boxes branches :162-164,:178-180 out of scope) */
+    /* ray_color camera.rs:153-186 */
     V3 ray_color(const Ray& r, uint32_t depth, uint32_t max_depth, int algorithm, uint64_t seed, uint32_t path_lo, uint32_t path_hi) {
         if (depth == 0) return v3(0, 0, 0);
         HitRecord rec;
         Interval it = {0.001, INF};
         if (world_hit(algorithm, r, it, rec)) {
+            if (rec.hits_aabb_edge) return v3(1.0, 0.0, 0.0);      /* :162-164 Color::red() vec3.rs:109 */
             Ray scattered = {v3(0, 0, 0), v3(0, 0, 0)};
             V3 attenuation = v3(0, 0, 0);
             if (rec.mat >= 0) {
@@ -559,6 +572,7 @@ struct Trace {
             }
             return v3(0, 0, 0);
         } else {
+            if (rec.hits_aabb_edge) return v3(1.0, 0.0, 0.0);      /* :178-180 */
             V3 unit_direction = unit(r.dir);
             double a = 0.5 * (unit_direction.y + 1.0);
             return (1.0 - a) * v3(1.0, 1.0, 1.0) + a * v3(0.5, 0.7, 1.0);
@@ -700,6 +714,8 @@ int orc_get_grid(const orc_scene* sc, double* cell_aabb, uint64_t* cell_offset, 
     return 0;
 }
 
+void orc_set_draw_boxes(orc_scene* sc, int on) { sc->draw_boxes = on != 0; }
+
 int orc_trace(const orc_scene* sc, int algorithm, const double* orig, const double* dir, uint64_t n, double tmin, double tmax,
               int32_t* out_prim, double* out_t, double* out_tp, uint8_t* out_hit, orc_counters* counters) {
     if (algorithm == ORC_ALGO_BVH && !sc->have_bvh) return -1;
@@ -712,7 +728,7 @@ int orc_trace(const orc_scene* sc, int algorithm, const double* orig, const doub
         if (out_prim) out_prim[i] = rec.prim;
         if (out_t) out_t[i] = rec.t;
         if (out_tp) out_tp[i] = rec.tp;
-        if (out_hit) out_hit[i] = h ? 1 : 0;
+        if (out_hit) out_hit[i] = (uint8_t)((h ? 1 : 0) | (rec.hits_aabb_edge ? 2 : 0));
     }
     if (counters) *counters = c;
     return 0;

@@ -71,9 +71,14 @@ uint64_t orc_grid_cell_count(const orc_scene*);
 uint64_t orc_grid_list_len(const orc_scene*);
 int orc_get_grid(const orc_scene*, double* cell_aabb /* n*6 */, uint64_t* cell_offset /* n+1 */, uint32_t* prim_list);
 
+/* Options.draw_boxes (`-o draw-boxes`, rtweekend.rs:92,128,146): every successful AABB test whose entry point lies on a box
+ * edge sets the sticky rec.hits_aabb_edge (aabb.rs:57-60,90-97) and ray_color returns red (camera.rs:162-164,178-180) */
+void orc_set_draw_boxes(orc_scene*, int on);
+
 /* one HittableList::hit (hittable_list.rs:65-102) per ray on a fresh HitRecord.
  * out_prim = original object index of the last accepted primitive (-1 if none accepted),
- * out_t = rec.t bits after the call, out_tp = t at which rec.p was last written, out_hit = return value. */
+ * out_t = rec.t bits after the call, out_tp = t at which rec.p was last written,
+ * out_hit = return value (bit 0) | rec.hits_aabb_edge << 1 (only ever set with draw_boxes on). */
 int orc_trace(const orc_scene*, int algorithm, const double* orig /* n*3 */, const double* dir /* n*3 */,
               uint64_t n, double tmin, double tmax,
               int32_t* out_prim, double* out_t, double* out_tp, uint8_t* out_hit, orc_counters* counters);

@@ -59,6 +59,7 @@ def lib():
         L.orc_grid_cell_count.argtypes = [C.c_void_p]; L.orc_grid_cell_count.restype = C.c_uint64
         L.orc_grid_list_len.argtypes = [C.c_void_p]; L.orc_grid_list_len.restype = C.c_uint64
         L.orc_get_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_draw_boxes.argtypes = [C.c_void_p, C.c_int]; L.orc_set_draw_boxes.restype = None
         L.orc_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
         L.orc_camera_init.argtypes = [C.POINTER(CameraIn), C.POINTER(CameraOut)]
@@ -112,6 +113,10 @@ class OracleScene:
         if rc: raise RuntimeError(f"orc_get_grid {rc}")
         return aabb, off, pl[:ll]
 
+    def set_draw_boxes(self, on):
+        lib().orc_set_draw_boxes(self._h, 1 if on else 0)
+        return self
+
     def trace(self, algorithm, orig, direction, tmin=0.001, tmax=float("inf")):
         orig = np.ascontiguousarray(orig, dtype=np.float64).reshape(-1, 3)
         direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
@@ -121,7 +126,7 @@ class OracleScene:
         rc = lib().orc_trace(self._h, ALGOS[algorithm], orig.ctypes.data, direction.ctypes.data, n, tmin, tmax,
                              prim.ctypes.data, t.ctypes.data, tp.ctypes.data, hit.ctypes.data, C.byref(c))
         if rc: raise RuntimeError(f"orc_trace {rc}")
-        return {"prim": prim, "t": t, "tp": tp, "hit": hit.astype(bool), "stats": c.as_dict()}
+        return {"prim": prim, "t": t, "tp": tp, "hit": (hit & 1).astype(bool), "edge": (hit & 2).astype(bool), "stats": c.as_dict()}
 
     def render(self, cam, algorithm, s_begin, s_count, max_depth, seed=1, rows=None, nthreads=1):
         H, W = cam.image_height, cam.image_width

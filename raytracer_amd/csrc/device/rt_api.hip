@@ -79,6 +79,7 @@ V3 tov(const double* p) { V3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
 struct rt_scene {
     uint32_t n_prims = 0, n_mats = 0;
     bool mixed = false;                // spheres and triangles together: shade needs the accept-time t as well
+    bool draw_boxes = false;           // Options.draw_boxes (rtweekend.rs:92)
     std::vector<rt_prim> h_prims;
     DPrim* d_prims = nullptr;          // file order (naive, grid)
     DMat* d_mats = nullptr;
@@ -129,8 +130,10 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
     switch (algorithm) {
     case RT_ALGO_BVH:
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
-        if (g_extend_variant == 1)
-            hipLaunchKernelGGL(k_extend_bvh, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+        if (sc->draw_boxes)            // debug overlay: the simple one-ray-per-thread kernel carries the edge flag
+            hipLaunchKernelGGL(k_extend_bvh<true>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+        else if (g_extend_variant == 1)
+            hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
         else
             hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
         break;
@@ -139,7 +142,10 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         break;
     case RT_ALGO_GRID:
         if (!sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called (reference: \"Please run Grid::new() first\")");
-        hipLaunchKernelGGL(k_extend_grid, grid, block, 0, st, sc->grid, sc->d_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+        if (sc->draw_boxes)
+            hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+        else
+            hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
         break;
     default:
         return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
@@ -206,7 +212,8 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
 
     const dim3 sgrid(g_stream_blocks), block(RT_SBLOCK);
     DRootBox rb; memset(&rb, 0, sizeof rb);
-    if (algorithm == RT_ALGO_BVH) { rb.enabled = 1; for (int c = 0; c < 3; ++c) { rb.mn[c] = sc->root_mn[c]; rb.mx[c] = sc->root_mx[c]; } }
+    // with draw-boxes the root test must also report its edge flag, so extend does it and generate culls nothing
+    if (algorithm == RT_ALGO_BVH && !sc->draw_boxes) { rb.enabled = 1; for (int c = 0; c < 3; ++c) { rb.mn[c] = sc->root_mn[c]; rb.mx[c] = sc->root_mx[c]; } }
     const DPrim* sprims = shade_prims(sc, algorithm);
     bool first = true;
     if (s_count == 0) HIPCHECK(hipMemsetAsync(d_fb, 0, WH * 3 * sizeof(double), st));
@@ -331,6 +338,13 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
     sc->ws.release();
     delete sc;
+}
+
+int rt_scene_set_options(rt_scene* sc, uint32_t flags) {
+    if (!sc) return fail(RT_E_ARG, "null argument");
+    if (flags & ~(uint32_t)RT_OPT_DRAW_BOXES) return fail(RT_E_ARG, "unknown option bits 0x%x", flags & ~(uint32_t)RT_OPT_DRAW_BOXES);
+    sc->draw_boxes = (flags & RT_OPT_DRAW_BOXES) != 0;
+    return RT_OK;
 }
 
 int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* prim_index, uint32_t n) {

@@ -192,6 +192,16 @@ RT_DEV bool ray_is_regular(V3 o, V3 inv) {
     return is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv.x) && is_finite(inv.y) && is_finite(inv.z);
 }
 
+// AABB::is_edge (aabb.rs:90-97): the point lies within 0.01 of a min or max face on at least two axes (draw-boxes only)
+RT_DEV bool box_is_edge(const double* mn, const double* mx, V3 p) {
+    const double pt[3] = {p.x, p.y, p.z};
+    int count = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if ((pt[a] <= mn[a] + 0.01 && pt[a] >= mn[a] - 0.01) || (pt[a] <= mx[a] + 0.01 && pt[a] >= mx[a] - 0.01)) ++count;
+    return count >= 2;
+}
+
 // value/material.rs:120-124; powi(5) expands to x * ((x*x)*(x*x))
 RT_DEV double reflectance(double cosine, double refraction_index) {
     double r0 = (1.0 - refraction_index) / (1.0 + refraction_index);

@@ -9,6 +9,8 @@
 struct RayQ { double *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb; uint32_t* id; };
 
 // where extend writes its result; trace != 0 selects the parity-entry format (rt_trace)
+// render format: prim = index of the last accepted primitive, -1 = miss, RT_HIT_EDGE = the ray touched a box edge (draw-boxes)
+#define RT_HIT_EDGE (-2)
 // tn (nullable) = t of the accepted primitive; only stored for scenes that mix spheres and triangles
 struct ExtendOut { int32_t* prim; double* t; double* tp; double* tn; uint8_t* hit; int trace; };
 
@@ -31,12 +33,15 @@ __global__ void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t
                            double* rad, uint64_t rad_stride, unsigned long long* stats);
 __global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, const uint32_t* pi, const uint32_t* pj,
                                 uint64_t n, double* orig, double* dir);
+// DRAW = Options.draw_boxes (rtweekend.rs:92): the sticky rec.hits_aabb_edge of aabb.rs:57-60 is tracked per ray
+template <bool DRAW>
 __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                              double tmin0, double tmax0, ExtendOut out, StackEntry* stack, unsigned long long* stats);
 __global__ void k_extend_bvh2(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
 __global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                                double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
+template <bool DRAW>
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_shade(const DPrim* prims, const DMat* mats, RayQ in, const uint32_t* count_in,

@@ -136,14 +136,16 @@ __global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, con
 // ---------------------------------------------------------------------------------------------
 // extend, common epilogue.  Render mode stores (hit ? prim : -1, tp); trace mode also stores rec.t and the
 // boolean, and maps the primitive back to its file-order index.
-RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState& rec, const DPrim* prims) {
+// `edge` = rec.hits_aabb_edge (draw-boxes only): bit 1 of the trace byte; in render mode it replaces the primitive, because
+// ray_color returns red whether or not anything was hit (camera.rs:162-164,178-180).
+RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState& rec, const DPrim* prims, bool edge = false) {
     if (out.trace) {
         if (out.prim) out.prim[q] = rec.prim >= 0 ? (int32_t)prims[rec.prim].orig : -1;
         if (out.t) out.t[q] = rec.t;
         if (out.tp) out.tp[q] = rec.tp;
-        if (out.hit) out.hit[q] = hit ? 1 : 0;
+        if (out.hit) out.hit[q] = (uint8_t)((hit ? 1 : 0) | (edge ? 2 : 0));
     } else {
-        out.prim[q] = hit ? rec.prim : -1;
+        out.prim[q] = edge ? RT_HIT_EDGE : (hit ? rec.prim : -1);
         out.tp[q] = rec.tp;
         if (out.tn) out.tn[q] = rec.tn;
     }
@@ -159,6 +161,7 @@ RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState
 //     one-bit flag saved/cleared at push and OR-restored at pop reproduces it;
 //   * the pending far child and its entry distance (bvh.rs:210-212): the 16-byte stack entry.
 // The stack lives in HBM as stack[level][thread] (coalesced across the wave); `stack_cap` is the tree depth.
+template <bool DRAW>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
                                                          RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                          double tmin0, double tmax0, ExtendOut out,
@@ -181,6 +184,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
         ++c_box;
         double e0 = tmin0, e1 = tmax0;
         bool go = slab(root.mn, root.mx, o, inv, e0, e1);
+        bool edge = false;
+        if (DRAW && go) edge = box_is_edge(root.mn, root.mx, o + e0 * d);      // aabb.rs:57-60
         uint32_t cur_a = root.a, cur_b = root.b;
         uint32_t sp = 0;
         bool flag = false, need_pop = false;
@@ -214,6 +219,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
                 double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
                 bool lh = slab(L.mn, L.mx, o, inv, ld, lx);
                 bool rh = slab(R.mn, R.mx, o, inv, rd, rx);
+                if (DRAW) {
+                    if (lh && box_is_edge(L.mn, L.mx, o + ld * d)) edge = true;
+                    if (rh && box_is_edge(R.mn, R.mx, o + rd * d)) edge = true;
+                }
                 if (lh && rh) {
                     bool right_first = ld >= rd;         // bvh.rs:210-211 (tie -> right is `close`)
                     StackEntry e;
@@ -229,13 +238,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh(const DNode* __restrict
                 else need_pop = true;
             }
         }
-        store_hit(out, q, rec.prim >= 0, rec, prims);
+        store_hit(out, q, rec.prim >= 0, rec, prims, edge);
     }
     if (stats) {
         stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
         stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
+template __global__ void k_extend_bvh<false>(const DNode*, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, unsigned long long*);
+template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, unsigned long long*);
 
 // extend_bvh, persistent form: the same continuation machine as k_extend_bvh (every decision, counter and
 // result is identical), restructured for a wave64 machine whose lanes finish at very different times:
@@ -461,6 +472,7 @@ RT_DEV uint64_t grid_cell_from_point(V3 p, const DGrid& g) {            // grid.
 
 // extend_grid: HittableList::hit, grid arm (hittable_list.rs:94-100) = Grid::hit (grid.rs:139-147):
 // get_box_enter (:119-129) then the tail-recursive traverse (:151-183) as a loop.
+template <bool DRAW>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* __restrict__ prims,
                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
         V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
         V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
         HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-        bool hit = false;
+        bool hit = false, edge = false;
         ++c_rays;
         // get_box_enter
         uint64_t cell = grid_cell_from_point(o, g);
@@ -512,6 +524,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
                 if (b < a) { ok = false; break; }
             }
             if (!ok) break;                                            // grid.rs:155-156
+            if (DRAW && box_is_edge(mn, mx, o + a * d)) edge = true;   // aabb.rs:57-60, on the real rec (grid.rs:155)
             // GridBox::hit on a copy of rec (grid.rs:160-167, 281-294)
             ++c_gbox;
             HitState copy = rec;
@@ -539,13 +552,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
             cell = grid_index(next_xyz - g.origin, g);                 // grid.rs:76-83
             if (cell >= g.n_cells) break;
         }
-        store_hit(out, q, hit, rec, prims);
+        store_hit(out, q, hit, rec, prims, edge);
     }
     if (stats) {
         stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
         stat_add(stats, ST_GRIDBOX, c_gbox); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
+template __global__ void k_extend_grid<false>(DGrid, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
+template __global__ void k_extend_grid<true>(DGrid, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
 
 // ---------------------------------------------------------------------------------------------
 // shade: the body of ray_color after world.hit (camera.rs:161-185) for one bounce, iteratively:
@@ -582,7 +597,9 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
             id = in.id[q];
             int32_t pi = hit_prim_[q];
             V3 radiance = v3(0, 0, 0);
-            if (pi < 0) {                                             // camera.rs:182-184
+            if (pi == RT_HIT_EDGE) {                                  // camera.rs:162-164,178-180: Color::red()
+                radiance = thr * v3(1.0, 0.0, 0.0);
+            } else if (pi < 0) {                                      // camera.rs:182-184
                 radiance = thr * sky_color(d);
             } else {
                 DPrim P = prims[pi];

@@ -152,7 +152,8 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
         err = "no scene file given: pass one of scenes/*.json or a PLY file (the built-in generators are not part of this build)";
         return 2;
     }
-    for (AlgorithmOption o : cli.options) if (o == OPT_DRAW_BOXES) { err = "option draw-boxes is not implemented on the GPU path yet"; return 2; }
+    bool draw_boxes = false;                             // Options::new rtweekend.rs:128
+    for (AlgorithmOption o : cli.options) if (o == OPT_DRAW_BOXES) draw_boxes = true;
 
     Scene scene;
     if (cli.format == FORMAT_NATIVE) { if (!load_json(cli.filename, scene, err)) return 1; }
@@ -191,6 +192,7 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     // world.init() main.rs:128 → hittable_list.rs:33-53 (host build, then flatten + upload)
     rt_scene* dev = rt_scene_create(scene.prims.data(), (uint32_t)scene.prims.size(), scene.mats.data(), (uint32_t)scene.mats.size());
     if (!dev) { err = rt_last_error(); return 3; }
+    if (rt_scene_set_options(dev, draw_boxes ? (uint32_t)RT_OPT_DRAW_BOXES : 0u) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
     if (cli.algorithm == RT_ALGO_BVH) {
         auto t = std::chrono::steady_clock::now();
         Bvh bvh;

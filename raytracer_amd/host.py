@@ -107,6 +107,7 @@ class HittableList:
         self.algorithm = "bvh"
         self.bvh_mode = "sah-position"
         self.grid_size = 25.0
+        self.draw_boxes = False          # Options.draw_boxes (rtweekend.rs:92), `-o draw-boxes`
         self.bvh = None
         self.grid = None
         self._dev = None
@@ -176,6 +177,7 @@ class HittableList:
             if not dev:
                 raise RtError(hip.rt_last_error().decode())
             self._dev = dev
+        _hip_check(hip.rt_scene_set_options(self._dev, F.RT_OPT_DRAW_BOXES if self.draw_boxes else 0))
         if self.bvh is not None:
             _hip_check(hip.rt_scene_set_bvh(self._dev, host.rth_bvh_nodes(self.bvh._h), self.bvh.n_nodes,
                                             host.rth_bvh_order(self.bvh._h), len(self)))
@@ -196,7 +198,7 @@ class HittableList:
         algo = self.ALGOS[algorithm or self.algorithm]
         _hip_check(F.hip_lib().rt_trace(self._dev, algo, orig.ctypes.data, direction.ctypes.data, n, tmin, tmax,
                                         prim.ctypes.data, t.ctypes.data, tp.ctypes.data, hit.ctypes.data, C.byref(st)))
-        return {"prim": prim, "t": t, "tp": tp, "hit": hit.astype(bool), "stats": st.as_dict()}
+        return {"prim": prim, "t": t, "tp": tp, "hit": (hit & 1).astype(bool), "edge": (hit & 2).astype(bool), "stats": st.as_dict()}
 
     def close(self):
         if self._dev is not None:

@@ -45,6 +45,16 @@ def test_reference_matrix_runs(gpu, tmp_path, scene, fmt, extra):
     assert r["algorithm"] in ("Naive", "BVH", "Grid")
 
 
-def test_draw_boxes_is_rejected_loudly(gpu, tmp_path):
-    with pytest.raises(rt.RtError, match="draw-boxes"):
-        rt.run(["scenes/simple_fuzzy_metal.json", "-o", "draw-boxes", "--output-dir", str(tmp_path)])
+@pytest.mark.parametrize("extra,name", [(["-o", "draw-boxes"], "simple_fuzzy_metal-bvh-DrawBoxes.ppm"),
+                                        (["-o", "bvh-sah-plane", "-o", "draw-boxes"], "simple_fuzzy_metal-bvh-BvhSahPlane_DrawBoxes.ppm"),
+                                        (["--algorithm", "grid", "-g", "5", "-o", "draw-boxes"], "simple_fuzzy_metal-grid-DrawBoxes_size=5.ppm")])
+def test_draw_boxes_overlay(gpu, tmp_path, extra, name):
+    """`-o draw-boxes` (rtweekend.rs:146): box edges are painted pure red (camera.rs:162-164,178-180); the option shows in the
+    file name (rtweekend.rs:97-113) and combines with a BVH build option (check_valid_options ignores it, rtweekend.rs:150-160)."""
+    out = str(tmp_path / "output")
+    assert rt.run(["scenes/simple_fuzzy_metal.json", "--width", "160", "--spp", "4", "--output-dir", out] + extra) == 0
+    assert os.listdir(out).count(name) == 1
+    px = np.array(open(os.path.join(out, name)).read().split()[4:], dtype=int).reshape(-1, 3)
+    red = (px[:, 0] == 255) & (px[:, 1] == 0) & (px[:, 2] == 0)
+    assert red.sum() > 0, "no pure-red edge pixel in the overlay"
+    assert "DrawBoxes" in list(csv.DictReader(open(os.path.join(out, "stats.csv"))))[0]["options"]
