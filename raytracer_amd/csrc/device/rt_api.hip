@@ -32,6 +32,7 @@ uint64_t g_batch_paths = 0;           // paths in flight per batch; 0 = size fro
 uint32_t g_tune = (16u << 16) | (1u << 8) | 2u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
 unsigned long long* g_dbg = nullptr;  // diagnostic builds (-DRT_STAMPS) only
 int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
+bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 
 struct EventPool {
     std::vector<hipEvent_t> ev; size_t used = 0;
@@ -85,7 +86,9 @@ struct rt_scene {
     DMat* d_mats = nullptr;
     // BVH
     bool have_bvh = false; uint32_t n_nodes = 0, bvh_depth = 0;
+    bool bvh_empty_leaf = false;       // a leaf without primitives (only the root of an empty scene): plain kernel only
     DNode* d_nodes = nullptr; DPrim* d_prims_bvh = nullptr; StackEntry* d_stack = nullptr;
+    DPair32* d_pairs32 = nullptr; DPrim32* d_prims32 = nullptr; double lattice_scale = 0.0;   // compact forms; scale 0 = not available
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     // grid
     bool have_grid = false; DGrid grid{};
@@ -94,6 +97,14 @@ struct rt_scene {
 };
 
 namespace {
+
+// c == (f64)f32 * S bit for bit?  (then the device can rebuild c from the f32 with the same two operations)
+bool on_lattice(double c, double S, float& f) {
+    if (!(c - c == 0.0)) return false;                 // inf / NaN
+    f = (float)(c / S);
+    const double back = (double)f * S;
+    return memcmp(&back, &c, sizeof c) == 0;
+}
 
 DPrim to_dprim(const rt_prim& p, uint32_t orig) {
     DPrim d; for (int i = 0; i < 9; ++i) d.v[i] = p.v[i];
@@ -132,10 +143,15 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
         if (sc->draw_boxes)            // debug overlay: the simple one-ray-per-thread kernel carries the edge flag
             hipLaunchKernelGGL(k_extend_bvh<true>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
-        else if (g_extend_variant == 1)
+        else if (g_extend_variant == 1 || sc->bvh_empty_leaf)
             hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
-        else
-            hipLaunchKernelGGL(k_extend_bvh2, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
+        else {
+            BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
+            if (g_compact && sc->lattice_scale > 0.0)
+                hipLaunchKernelGGL(k_extend_bvh2<true>, grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
+            else
+                hipLaunchKernelGGL(k_extend_bvh2<false>, grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
+        }
         break;
     case RT_ALGO_NAIVE:
         hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->n_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
@@ -277,6 +293,7 @@ int rt_init(int device) {
     }
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
+    if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
 #ifdef RT_STAMPS
@@ -335,6 +352,7 @@ void rt_scene_destroy(rt_scene* sc) {
 #endif
     if (sc->d_prims) (void)hipFree(sc->d_prims); if (sc->d_mats) (void)hipFree(sc->d_mats);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
+    if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
     sc->ws.release();
     delete sc;
@@ -354,7 +372,7 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     // validate shape on the host: the kernel trusts indices, sibling adjacency and the depth bound
     std::vector<uint8_t> seen(n_nodes, 0);
     std::vector<std::pair<uint32_t, uint32_t>> todo; todo.push_back({0u, 1u});
-    uint32_t depth = 0; uint64_t covered = 0;
+    uint32_t depth = 0; uint64_t covered = 0; bool empty_leaf = false;
     while (!todo.empty()) {
         auto [i, d] = todo.back(); todo.pop_back();
         if (i >= n_nodes) return fail(RT_E_ARG, "node index %u out of range", i);
@@ -363,7 +381,7 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
         const rt_bvh_node& nd = nodes[i];
         if (nd.is_leaf) {
             if ((uint64_t)nd.first + nd.count > n) return fail(RT_E_ARG, "leaf %u covers [%u,%u) of %u objects", i, nd.first, nd.first + nd.count, n);
-            covered += nd.count;
+            covered += nd.count; if (nd.count == 0) empty_leaf = true;
         } else {
             if (nd.right != nd.left + 1) return fail(RT_E_ARG, "node %u: children %u,%u are not adjacent (bvh.rs:167-168 makes them so)", i, nd.left, nd.right);
             todo.push_back({nd.right, d + 1}); todo.push_back({nd.left, d + 1});
@@ -383,14 +401,46 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     std::vector<DPrim> dp(n ? n : 1);
     for (uint32_t k = 0; k < n; ++k) dp[k] = to_dprim(sc->h_prims[prim_index[k]], prim_index[k]);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
-    sc->d_nodes = nullptr; sc->d_prims_bvh = nullptr; sc->d_stack = nullptr; sc->have_bvh = false;
+    if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
+    sc->d_nodes = nullptr; sc->d_prims_bvh = nullptr; sc->d_stack = nullptr; sc->d_pairs32 = nullptr; sc->d_prims32 = nullptr; sc->lattice_scale = 0.0; sc->have_bvh = false;
     HIPCHECK(hipMalloc(&sc->d_nodes, dn.size() * sizeof(DNode)));
     HIPCHECK(hipMalloc(&sc->d_prims_bvh, dp.size() * sizeof(DPrim)));
     HIPCHECK(hipMalloc(&sc->d_stack, (size_t)depth * g_extend_blocks * RT_BLOCK * sizeof(StackEntry)));
     HIPCHECK(hipMemcpy(sc->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(sc->d_prims_bvh, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    // compact forms: all triangles, and every box plane and vertex coordinate on one f32 lattice (scale 100 = PLY, or 1)
+    for (double S : {100.0, 1.0}) {
+        bool ok = n > 0 && !empty_leaf;
+        std::vector<DPair32> pairs(((size_t)n_nodes + 2) / 2);
+        std::vector<DPrim32> tris(n);
+        for (auto& pr : pairs) memset(&pr, 0, sizeof pr);
+        for (size_t p = 0; ok && p < pairs.size(); ++p) {
+            for (int side = 0; ok && side < 2; ++side) {
+                const size_t di = 2 * p + side;
+                if (di == 0 || di > n_nodes) continue;
+                const DNode& nd = dn[di];
+                float* box = pairs[p].box + 6 * side;
+                for (int c = 0; ok && c < 3; ++c) ok = on_lattice(nd.mn[c], S, box[c]) && on_lattice(nd.mx[c], S, box[3 + c]);
+                const uint32_t a = (nd.b & RT_LEAF) ? nd.a : nd.a >> 1;      // internal child: index of ITS children's pair
+                if (side == 0) { pairs[p].la = a; pairs[p].lb = nd.b; } else { pairs[p].ra = a; pairs[p].rb = nd.b; }
+            }
+        }
+        for (uint32_t k = 0; ok && k < n; ++k) {
+            const rt_prim& t = sc->h_prims[prim_index[k]];
+            ok = t.type == RT_TRIANGLE;
+            for (int c = 0; ok && c < 9; ++c) ok = on_lattice(t.v[c], S, tris[k].v[c]);
+            tris[k].tm = dp[k].tm; tris[k].orig = dp[k].orig; tris[k].pad = 0;
+        }
+        if (!ok) continue;
+        HIPCHECK(hipMalloc(&sc->d_pairs32, pairs.size() * sizeof(DPair32)));
+        HIPCHECK(hipMalloc(&sc->d_prims32, tris.size() * sizeof(DPrim32)));
+        HIPCHECK(hipMemcpy(sc->d_pairs32, pairs.data(), pairs.size() * sizeof(DPair32), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(sc->d_prims32, tris.data(), tris.size() * sizeof(DPrim32), hipMemcpyHostToDevice));
+        sc->lattice_scale = S;
+        break;
+    }
     for (int c = 0; c < 3; ++c) { sc->root_mn[c] = nodes[0].min[c]; sc->root_mx[c] = nodes[0].max[c]; }
-    sc->n_nodes = n_nodes; sc->bvh_depth = depth; sc->have_bvh = true;
+    sc->n_nodes = n_nodes; sc->bvh_depth = depth; sc->bvh_empty_leaf = empty_leaf; sc->have_bvh = true;
     (void)covered;
     return RT_OK;
 }

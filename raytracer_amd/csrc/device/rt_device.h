@@ -96,6 +96,14 @@ struct __align__(8) DMat { double albedo[3]; double param; uint32_t type; uint32
 //   leaf:     a = first object (index into the BVH-ordered DPrim array), b = count | RT_LEAF
 struct __align__(16) DNode { double mn[3]; double mx[3]; uint32_t a, b, pad0, pad1; };
 #define RT_LEAF 0x80000000u
+// Compact forms for scenes whose coordinates all lie on an f32 lattice, c == (f64)f32 * scale bit for bit (PLY meshes:
+// parser.rs:67-73 widens f32 vertices and multiplies by 100; box planes are min/max of vertex coordinates, so they lie on
+// the same lattice).  The device widens and scales with the same two IEEE operations, so every value it computes with is
+// identical to the f64 one — the point is that a divergent 16-byte lane access costs the vector L1 one cycle each, and a
+// sibling pair is then 4 accesses instead of 8, a triangle 3 instead of 6.
+//   DPair32: children of one internal node.  a/b as in DNode, except that an internal child's `a` is a pair index.
+struct __align__(16) DPair32 { float box[12]; uint32_t la, lb, ra, rb; };      // box: L.mn, L.mx, R.mn, R.mx
+struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; };          // triangles only
 
 // The part of HitRecord (hittable.rs:13-21) that survives a hit() call and that later code reads:
 // rec.t (read back as closest_so_far, bvh.rs:200,215 / grid.rs:164), the t at which rec.p was last written
@@ -149,6 +157,39 @@ RT_DEV bool hit_triangle(const DPrim& tr, int32_t index, V3 o, V3 d, double tmin
     rec.prim = index; rec.tn = t;
     return true;
 }
+// hit_triangle without early returns, for the persistent extend kernel: a wave runs the test with dozens of lanes, so a
+// lane's early-out saves nothing (the wave executes every level anyway) and each nested exit costs mask bookkeeping.
+// Same arithmetic, same order; the record is updated through selects.  (NaN: `t < 0.0` and `x <= 0.0` are false for
+// NaN in the reference as well, so the negated forms below keep its behaviour.)
+RT_DEV bool hit_triangle_flat(const DPrim& tr, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    V3 v0 = v3(tr.v[0], tr.v[1], tr.v[2]), v1 = v3(tr.v[3], tr.v[4], tr.v[5]), v2 = v3(tr.v[6], tr.v[7], tr.v[8]);
+    V3 v0v1 = v1 - v0;
+    V3 v0v2 = v2 - v0;
+    V3 n = cross(v0v1, v0v2);
+    double n_dot_dir = dot(n, d);
+    const bool c1 = tmin < n_dot_dir && n_dot_dir < tmax;                 // :44-47
+    double dd = -dot(n, v0);
+    double t = -(dot(n, o) + dd) / n_dot_dir;                             // :52
+    const bool c2 = c1 && !(t < 0.0);                                     // :55-57
+    V3 p = o + (t * d);
+    V3 v0p = p - v0;
+    const bool e0 = !(dot(n, cross(v0v1, v0p)) <= 0.0);                   // :62-65
+    V3 v1v2 = v2 - v1;
+    V3 v1p = p - v1;
+    const bool e1 = !(dot(n, cross(v1v2, v1p)) <= 0.0);                   // :67-70
+    V3 v2v0 = v0 - v2;
+    V3 v2p = p - v2;
+    const bool e2 = !(dot(n, cross(v2v0, v2p)) <= 0.0);                   // :72-75
+    const bool acc = c2 && e0 && e1 && e2;
+    rec.t = c1 ? t : rec.t;
+    rec.tp = c2 ? t : rec.tp;
+    rec.tn = acc ? t : rec.tn;
+    rec.prim = acc ? index : rec.prim;
+    return acc;
+}
+RT_DEV bool hit_prim_flat(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    return (p.tm >> 31) ? hit_triangle_flat(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
+}
 RT_DEV bool hit_prim(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
     return (p.tm >> 31) ? hit_triangle(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
 }
@@ -177,14 +218,18 @@ RT_DEV bool slab(const double* mn, const double* mx, V3 o, V3 inv, double& tmin,
 // A NaN t0/t1 needs 0 * inf, i.e. a non-finite 1/dir component (dir component zero, denormal or NaN) or a
 // non-finite origin: rays for which ray_is_regular() is false must use slab().  (Signed zeros: min/max may pick
 // either zero of an equal pair; the interval ends are only ever compared, and tmin >= 0.001, so it cannot matter.)
+// The instructions are named directly: fmin()/fmax() make the compiler canonicalise every operand first (one extra
+// v_max_f64 x,x each), which only matters for signalling NaNs and no NaN reaches this path.
+RT_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_DEV bool slab_fast(const double* mn, const double* mx, V3 o, V3 inv, double& tmin, double& tmax) {
     double t0, t1;
     t0 = (mn[0] - o.x) * inv.x; t1 = (mx[0] - o.x) * inv.x;
-    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
     t0 = (mn[1] - o.y) * inv.y; t1 = (mx[1] - o.y) * inv.y;
-    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
     t0 = (mn[2] - o.z) * inv.z; t1 = (mx[2] - o.z) * inv.z;
-    tmin = fmax(tmin, fmin(t0, t1)); tmax = fmin(tmax, fmax(t0, t1));
+    tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
     return !(tmax < tmin);
 }
 RT_DEV bool is_finite(double x) { return fabs(x) < __builtin_huge_val(); }     // false for inf and NaN

@@ -250,15 +250,13 @@ template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, co
 
 // extend_bvh, persistent form: the same continuation machine as k_extend_bvh (every decision, counter and
 // result is identical), restructured for a wave64 machine whose lanes finish at very different times:
-//   * a wave keeps its 64 lanes fed: when >= RT_REFILL lanes are idle it pulls fresh rays for them from the
+//   * a wave keeps its 64 lanes fed: when enough lanes (tune bits 16..23) are idle it pulls fresh rays for them from the
 //     queue (one atomic per chunk of rays per wave), instead of waiting for its slowest lane;
 //   * one loop iteration = [internal-node visit for every lane] then [leaf tests and stack pops until the lane
 //     stands on an internal node again], so the expensive two-box visit always runs with all live lanes;
 //   * the continuation stack's top RT_STK entries live in LDS ([level][lane]: conflict-free for b64 and b32
 //     accesses whatever level each lane is on); deeper entries spill to HBM as stack[level][thread].
 #define RT_STK 8
-#define RT_LEAF_STARTED 0x20000000u   // cur_b of a leaf being processed: bit 29 = its traversal step has been counted
-#define RT_LEAF_COUNT 0x1fffffffu     //                                      bits 0..28 = primitives still to test
 // Diagnostic build only (-DRT_STAMPS): per-wave cycle sums per phase of the loop, added into dbg[] at the end.
 // dbg: 0 loop cycles, 1 refill cycles, 2 internal cycles, 3 leaf cycles, 4 iterations, 5 refill iterations, 6 internal
 // iterations, 7 leaf iterations, 8 lanes served by internal phases, 9 lanes served by leaf phases, 10 lanes refilled,
@@ -270,16 +268,24 @@ template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, co
 #define RT_STAMP_DECL
 #define RT_STAMP(x)
 #endif
-#define RT_REFILL 16
-#define RT_COST_INT 1u    // relative instruction cost of the two phases, for the vote
-#define RT_COST_LEAF 2u
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restrict__ nodes, const DPrim* __restrict__ prims,
-                                                          RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+// wave64 ballot of a predicate that already lives in a lane mask: one s_and with exec (HIP's __ballot(int) first
+// materialises the bool as 0/1 in a VGPR and compares it again)
+RT_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+RT_DEV uint32_t popc64(unsigned long long m) { return (uint32_t)__builtin_popcountll(m); }
+
+RT_DEV double lattice(uint32_t f32_bits, double scale) { return (double)__uint_as_float(f32_bits) * scale; }
+
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4
+#endif
+template <bool C32>
+__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out,
                                                           StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
                                                           unsigned long long* dbg) {
     RT_STAMP_DECL
-    const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu, refill_min = (tune >> 16) & 0xffu;
+    const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu;
+    const uint32_t refill_min = ((tune >> 16) & 0xffu) > 64u ? 64u : ((tune >> 16) & 0xffu);   // a fully idle wave always refills
     __shared__ double s_fd[RT_STK][RT_BLOCK];
     __shared__ uint2 s_ab[RT_STK][RT_BLOCK];
     const uint32_t n = count ? *count : (uint32_t)n_fixed;
@@ -289,7 +295,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
     uint32_t c_next = 0, c_end = 0;          // wave-uniform: the wave's current chunk of the queue
     bool exhausted = false;
-    uint32_t c_box = 0, c_prim = 0, c_steps = 0, c_overlap = 0, c_rays = 0;
+    bool look_for_rays = true;               // wave-uniform: lanes went idle since the last refill decision
+    // counters: box tests = 2 per internal visit + 1 per ray (root); traversal steps = internal visits + leaves
+    uint32_t c_int = 0, c_leaf = 0, c_prim = 0, c_overlap = 0, c_rays = 0;
 
     bool active = false, need_pop = false, regular = true, all_regular = true;
     uint32_t q = 0, cur_a = 0, cur_b = 0, sp = 0, lo = 0;
@@ -297,57 +305,80 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
     double tmax = tmax0;
     HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+    const DNode* __restrict__ nodes = bvh.nodes; const DPrim* __restrict__ prims = bvh.prims;
     const DNode root = nodes[1];                 // device node i+1 = host node i (pairs 128-byte aligned)
+    const uint32_t root_a = (C32 && !(root.b & RT_LEAF)) ? root.a >> 1 : root.a;
+    const double scale = bvh.scale;
 
     for (;;) {
-        // ---- refill idle lanes
-        const unsigned long long idle = __ballot(!active);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        // ---- refill idle lanes (looked at only after lanes have finished: nothing else changes the idle set)
         RT_STAMP(tk0 = clock64(); ++n_it;)
-        if (n_idle && !exhausted && (n_idle >= refill_min)) {
-            RT_STAMP(++n_ref;)
-            if (c_next >= c_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) { exhausted = true; c_next = c_end = n; }
-                else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
+        if (look_for_rays) {
+            const unsigned long long idle = ballot64(!active);
+            const uint32_t n_idle = popc64(idle);
+            if (!exhausted && n_idle >= refill_min) {
+                RT_STAMP(++n_ref;)
+                if (c_next >= c_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n) { exhausted = true; c_next = c_end = n; }
+                    else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
+                }
+                const uint32_t avail = c_end - c_next;
+                const uint32_t rank = popc64(idle & ((1ull << lane) - 1ull));
+                if (!active && rank < avail) {
+                    q = c_next + rank;
+                    o = v3(in.ox[q], in.oy[q], in.oz[q]);
+                    d = v3(in.dx[q], in.dy[q], in.dz[q]);
+                    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                    regular = ray_is_regular(o, inv);
+                    rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+                    ++c_rays;
+                    tmax = tmax0; sp = 0; lo = 0; flag = false; need_pop = false;
+                    double e0 = tmin0, e1 = tmax0;
+                    if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root_a; cur_b = root.b; }   // bvh.rs:84-85
+                    else store_hit(out, q, false, rec, prims);
+                }
+                const uint32_t taken = (n_idle < avail) ? n_idle : avail;
+                c_next += taken;
+                // a chunk that ran out mid-refill leaves lanes idle: look again next iteration (the next chunk is fetched then)
+                look_for_rays = !exhausted && taken < n_idle;
+                all_regular = ballot64(active && !regular) == 0;     // min/max box test is exact only for regular rays
+                RT_STAMP(l_ref += taken; tk_ref += clock64() - tk0;)
+            } else {
+                look_for_rays = false;
             }
-            const uint32_t avail = c_end - c_next;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && rank < avail) {
-                q = c_next + rank;
-                o = v3(in.ox[q], in.oy[q], in.oz[q]);
-                d = v3(in.dx[q], in.dy[q], in.dz[q]);
-                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                regular = ray_is_regular(o, inv);
-                rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-                ++c_rays; ++c_box;
-                tmax = tmax0; sp = 0; lo = 0; flag = false; need_pop = false;
-                double e0 = tmin0, e1 = tmax0;
-                if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root.a; cur_b = root.b; }   // bvh.rs:84-85
-                else store_hit(out, q, false, rec, prims);
-            }
-            c_next += (n_idle < avail) ? n_idle : avail;
-            all_regular = !__any(active && !regular);    // min/max box test is exact only for regular rays
-            RT_STAMP(l_ref += (n_idle < avail) ? n_idle : avail; tk_ref += clock64() - tk0;)
+            if (ballot64(active) == 0) { if (exhausted) break; look_for_rays = true; continue; }
         }
-        if (!__any(active)) { if (exhausted) break; continue; }
 
         // ---- phase vote.  A lane is either on an internal node (wants the two-box visit) or on a leaf / waiting
         // to pop (wants the primitive tests + stack work).  Running both every iteration leaves most lanes masked
         // in one of them; instead the wave runs the phase that serves more lanes per instruction and the others wait.
         const bool want_leaf = active && (need_pop || (cur_b & RT_LEAF));
-        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
-        const uint32_t n_int = (uint32_t)__popcll(__ballot(active && !want_leaf));
+        const uint32_t n_leaf = popc64(ballot64(want_leaf));
+        const uint32_t n_int = popc64(ballot64(active && !want_leaf));
         RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
         if (n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int)) {   // never starve: one side is non-empty
             // ---- one internal-node visit (bvh.rs:203-229), branch-free apart from the push
             if (active && !want_leaf) {
-                ++c_steps;                               // bvh.rs:190
-                const DNode* pair = nodes + cur_a;       // siblings are adjacent: one 128-byte fetch
-                const DNode L = pair[0], R = pair[1];
-                c_box += 2;
+                ++c_int;                                 // bvh.rs:190 (and two box tests, bvh.rs:183)
+                struct { double mn[3], mx[3]; uint32_t a, b; } L, R;
+                if (C32) {                               // 64-byte pair: four 16-byte accesses
+                    const uint4* pp = (const uint4*)(bvh.pairs32 + cur_a);
+                    const uint4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
+                    L.mn[0] = lattice(q0.x, scale); L.mn[1] = lattice(q0.y, scale); L.mn[2] = lattice(q0.z, scale);
+                    L.mx[0] = lattice(q0.w, scale); L.mx[1] = lattice(q1.x, scale); L.mx[2] = lattice(q1.y, scale);
+                    R.mn[0] = lattice(q1.z, scale); R.mn[1] = lattice(q1.w, scale); R.mn[2] = lattice(q2.x, scale);
+                    R.mx[0] = lattice(q2.y, scale); R.mx[1] = lattice(q2.z, scale); R.mx[2] = lattice(q2.w, scale);
+                    L.a = q3.x; L.b = q3.y; R.a = q3.z; R.b = q3.w;
+                } else {                                 // siblings are adjacent: one 128-byte fetch, eight accesses
+                    const DNode* pair = nodes + cur_a;
+                    const DNode l = pair[0], r = pair[1];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { L.mn[c] = l.mn[c]; L.mx[c] = l.mx[c]; R.mn[c] = r.mn[c]; R.mx[c] = r.mx[c]; }
+                    L.a = l.a; L.b = l.b; R.a = r.a; R.b = r.b;
+                }
                 double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
                 bool lh, rh;
                 if (all_regular) { lh = slab_fast(L.mn, L.mx, o, inv, ld, lx); rh = slab_fast(R.mn, R.mx, o, inv, rd, rx); }
@@ -361,7 +392,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
                         my_spill[(uint64_t)lo * T] = e; ++lo;
                     }
                     const uint32_t s = sp & (RT_STK - 1);
-                    s_fd[s][tx] = fmax(ld, rd);          // bvh.rs:212
+                    s_fd[s][tx] = ld >= rd ? ld : rd;    // bvh.rs:212 f64::max of two non-NaN values
                     s_ab[s][tx] = make_uint2(go_right ? L.a : R.a, (go_right ? L.b : R.b) | (flag ? 0x40000000u : 0u));
                     ++sp; flag = false;
                 }
@@ -370,37 +401,50 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
             }
             RT_STAMP(++n_intp; l_int += n_int; tk_int += clock64() - tk0;)
         } else {
-            if (want_leaf) {
-            // ---- leaf tests (bvh.rs:195-202), then pops until the lane has a node again or its ray is finished
-            // one primitive per call: 96 % of the leaves hold one primitive, and a lane that has more keeps its place
-            // (cur_a / count in cur_b advance) and joins the next leaf phase, instead of making the whole wave loop.
+            // ---- one primitive test of the leaf (bvh.rs:195-202), then pops until the lane has a node again or its
+            // ray is finished.  One primitive per call: 96 % of the leaves hold one primitive, and a lane that has more
+            // keeps its place (cur_a / count in cur_b advance) and joins the next leaf phase instead of making the wave loop.
             // closest_so_far of the leaf (bvh.rs:193,200) lives in tmax: once a primitive is accepted the frame's old
             // tmax is dead (every later entry into a node goes through a pop with close_hit set, which reloads it).
-            if (!need_pop) {
-                if (!(cur_b & RT_LEAF_STARTED)) { ++c_steps; cur_b |= RT_LEAF_STARTED; }   // bvh.rs:190, once per leaf
-                ++c_prim;
-                const DPrim P = prims[cur_a];
-                if (hit_prim(P, (int32_t)cur_a, o, d, tmin0, tmax, rec)) { flag = true; tmax = rec.t; }
-                ++cur_a; --cur_b;
-                need_pop = (cur_b & RT_LEAF_COUNT) == 0;
-            }
-            while (need_pop) {
-                if (sp == 0) {
-                    store_hit(out, q, rec.prim >= 0, rec, prims);
-                    active = false; need_pop = false;
-                } else {
-                    --sp;
-                    double far_d; uint32_t ea, eb;
-                    if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ea = e.a; eb = e.b; }
-                    else { const uint32_t s = sp & (RT_STK - 1); far_d = s_fd[s][tx]; ea = s_ab[s][tx].x; eb = s_ab[s][tx].y; }
-                    const bool close_hit = flag;
-                    flag = flag | ((eb >> 30) & 1u);
-                    if (close_hit) {                     // bvh.rs:213-222
-                        if (far_d < rec.t) { ++c_overlap; tmax = rec.t; cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }
-                    } else { cur_a = ea; cur_b = eb & ~0x40000000u; need_pop = false; }   // bvh.rs:223
+            bool done = false;
+            if (want_leaf) {
+                if (!need_pop) {
+                    ++c_prim;
+                    bool acc;
+                    if (C32) {                           // 48-byte triangle: three 16-byte accesses
+                        const uint4* tp = (const uint4*)(bvh.prims32 + cur_a);
+                        const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                        DPrim P;
+                        P.v[0] = lattice(q0.x, scale); P.v[1] = lattice(q0.y, scale); P.v[2] = lattice(q0.z, scale);
+                        P.v[3] = lattice(q0.w, scale); P.v[4] = lattice(q1.x, scale); P.v[5] = lattice(q1.y, scale);
+                        P.v[6] = lattice(q1.z, scale); P.v[7] = lattice(q1.w, scale); P.v[8] = lattice(q2.x, scale);
+                        acc = hit_triangle_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
+                    } else {
+                        const DPrim P = prims[cur_a];
+                        acc = hit_prim_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
+                    }
+                    flag = flag || acc; tmax = acc ? rec.t : tmax;
+                    ++cur_a; --cur_b;                    // leaves hold >= 1 primitive (checked by rt_scene_set_bvh)
+                    need_pop = (cur_b & 0x3fffffffu) == 0;
+                    c_leaf += need_pop ? 1u : 0u;        // bvh.rs:190, once per leaf
                 }
+                while (need_pop) {
+                    if (sp == 0) { done = true; need_pop = false; }
+                    else {
+                        --sp;
+                        const uint32_t s = sp & (RT_STK - 1);
+                        double far_d = s_fd[s][tx]; uint2 ab = s_ab[s][tx];
+                        if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ab.x = e.a; ab.y = e.b; }
+                        const bool close_hit = flag;
+                        flag = flag || ((ab.y >> 30) & 1u);
+                        const bool overlap = close_hit && far_d < rec.t;      // bvh.rs:213-222
+                        if (overlap) { ++c_overlap; tmax = rec.t; }
+                        if (overlap || !close_hit) { cur_a = ab.x; cur_b = ab.y & ~0x40000000u; need_pop = false; }   // :219 / :223
+                    }
+                }
+                if (done) { store_hit(out, q, rec.prim >= 0, rec, prims); active = false; }
             }
-            }
+            look_for_rays = ballot64(done) != 0;
             RT_STAMP(++n_leafp; l_leaf += n_leaf; tk_leaf += clock64() - tk0;)
         }
     }
@@ -411,10 +455,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_bvh2(const DNode* __restric
     }
 #endif
     if (stats) {
-        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
+        stat_add(stats, ST_BOX, (uint64_t)c_int * 2u + c_rays); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, (uint64_t)c_int + c_leaf);
         stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
+template __global__ void k_extend_bvh2<false>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
+template __global__ void k_extend_bvh2<true>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
 
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, uint32_t n_prims,

@@ -37,6 +37,7 @@ void rth_scene_append(void* h, const void* other) {
     a.mats.insert(a.mats.end(), b.mats.begin(), b.mats.end());
     for (rt_prim p : b.prims) { p.material += base; a.prims.push_back(p); }
     a.centroids.insert(a.centroids.end(), b.centroids.begin(), b.centroids.end());
+    if (a.vertex_lattice != b.vertex_lattice) a.vertex_lattice = 0.0;
 }
 uint32_t rth_scene_n_prims(const void* h) { return (uint32_t)((const Scene*)h)->prims.size(); }
 uint32_t rth_scene_n_mats(const void* h) { return (uint32_t)((const Scene*)h)->mats.size(); }

@@ -270,10 +270,16 @@ bool load_ply(const std::string& path, const rt_material& mat, Scene& out, std::
     }
     if (!have_v) { err = "Parse error No vertices in PLY file"; return false; }
     if (!have_f) { err = "Parse error No faces in PLY file"; return false; }
+    out.vertex_lattice = 100.0;
     return true;
 }
 
 void subdivide_triangles(Scene& sc, int levels) {
+    const double S = sc.vertex_lattice;
+    auto mid = [S](double x, double y) {
+        double m = 0.5 * (x + y);
+        return S > 0.0 ? (double)(float)(m / S) * S : m;
+    };
     for (int l = 0; l < levels; ++l) {
         std::vector<rt_prim> np; std::vector<double> nc;
         np.reserve(sc.prims.size() * 4); nc.reserve(sc.centroids.size() * 4);
@@ -281,7 +287,7 @@ void subdivide_triangles(Scene& sc, int levels) {
             const rt_prim& p = sc.prims[i];
             if (p.type != RT_TRIANGLE) { np.push_back(p); nc.insert(nc.end(), &sc.centroids[3 * i], &sc.centroids[3 * i] + 3); continue; }
             double a[3], b[3], c[3], ab[3], bc[3], ca[3];
-            for (int k = 0; k < 3; ++k) { a[k] = p.v[k]; b[k] = p.v[3 + k]; c[k] = p.v[6 + k]; ab[k] = 0.5 * (a[k] + b[k]); bc[k] = 0.5 * (b[k] + c[k]); ca[k] = 0.5 * (c[k] + a[k]); }
+            for (int k = 0; k < 3; ++k) { a[k] = p.v[k]; b[k] = p.v[3 + k]; c[k] = p.v[6 + k]; ab[k] = mid(a[k], b[k]); bc[k] = mid(b[k], c[k]); ca[k] = mid(c[k], a[k]); }
             const double* tri[4][3] = {{a, ab, ca}, {ab, b, bc}, {ca, bc, c}, {ab, bc, ca}};   // same winding as the parent
             for (auto& t : tri) {
                 rt_prim q = p; double ce[3];

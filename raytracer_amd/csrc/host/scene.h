@@ -18,6 +18,7 @@ struct Scene {
     std::vector<double> centroids;       // Hittable::centroid() per object, xyz interleaved
     std::vector<rt_material> mats;
     std::string filename;                // as given on the command line (camera presets key on its prefix)
+    double vertex_lattice = 0.0;         // PLY: every coordinate is (f64)f32 * 100 (parser.rs:67-73) -> 100; 0 = arbitrary f64
 };
 
 // serde_json::from_reader into HittableList (main.rs:36-41; typetag tags hittable.rs:32, material.rs:15)
@@ -25,7 +26,9 @@ bool load_json(const std::string& path, Scene& out, std::string& err);
 // parse_ply (utils/parser.rs:15-81): f32 vertices widened and scaled by 100, 3-gon faces, one shared material
 bool load_ply(const std::string& path, const rt_material& mat, Scene& out, std::string& err);
 // Synthetic refinement (NOT a reference feature; used only to stand in for the absent full-resolution
-// dragon): every triangle is split into 4 by edge midpoints, `levels` times.  Spheres are kept.
+// dragon): every triangle is split into 4 by edge midpoints, `levels` times.  Spheres are kept.  For a PLY mesh the
+// midpoints are rounded onto the file format's own lattice ((f64)f32 * 100), so the result is what a finer PLY file
+// would have produced — a mesh whose coordinates a PLY could not hold would not stand in for one.
 void subdivide_triangles(Scene& sc, int levels);
 
 enum BvhMode { BVH_SAH_POSITION = 0, BVH_SAH_PLANE = 1, BVH_NAIVE = 2 };   // rtweekend.rs:137-147

@@ -3,18 +3,22 @@
 //  mode 1: cooperative: 8 lanes fetch one pair as a contiguous 128 B (8 loads per wave cover 64 pairs), staged through LDS
 //          (ds_write_b128, XOR-swizzled) and read back by the owning lane (8 x ds_read_b128)
 //  mode 2: cooperative with global_load_lds_dwordx4 (LDS-DMA, swizzle applied on the source side)
+//  mode 3: each lane loads a 64-byte pair (12 x f32 box planes + 4 x u32) with 4 x global_load_dwordx4 and widens to f64
 // The next index depends on the loaded data (dependent chain like a traversal).  Build: hipcc --offload-arch=gfx950 -O3
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include <cstdint>
+#include <cstring>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 struct __align__(16) Pair { double v[12]; uint32_t a, b, c, d; uint32_t pad[4]; };   // 128 B
 static_assert(sizeof(Pair) == 128, "");
 
-template <int MODE>
+//  LANES_ON < 64: only lanes with (lane % 64) < LANES_ON (mode 10+: every (64/LANES_ON)-th lane) take part: does a masked lane cost?
+template <int MODE, int LANES_ON = 64, bool STRIDED = false>
 __global__ __launch_bounds__(128) void k(const Pair* __restrict__ t, uint32_t n_pairs, int iters, double* out) {
+    if (STRIDED ? ((threadIdx.x & 63) % (64 / LANES_ON)) != 0 : (int)(threadIdx.x & 63) >= LANES_ON) return;
     __shared__ __align__(16) char lds[2][64 * 128];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t idx = (blockIdx.x * 128 + threadIdx.x) * 2654435761u % n_pairs;
@@ -22,7 +26,14 @@ __global__ __launch_bounds__(128) void k(const Pair* __restrict__ t, uint32_t n_
     char* base = lds[wv];
     for (int it = 0; it < iters; ++it) {
         double v[12]; uint32_t a, b;
-        if (MODE == 0) {
+        if (MODE == 3) {
+            const uint4* p4 = (const uint4*)((const char*)t + (size_t)idx * 64);
+            const uint4 q0 = p4[0], q1 = p4[1], q2 = p4[2], q3 = p4[3];
+            const float* f = (const float*)&q0; const float* g = (const float*)&q1; const float* h = (const float*)&q2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = (double)f[i] * 100.0; v[4 + i] = (double)g[i] * 100.0; v[8 + i] = (double)h[i] * 100.0; }
+            a = q3.x; b = q3.y;
+        } else if (MODE == 0) {
             const Pair p = t[idx];
 #pragma unroll
             for (int i = 0; i < 12; ++i) v[i] = p.v[i];
@@ -74,18 +85,32 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&d, n_pairs * sizeof(Pair))); CHECK(hipMalloc(&out, blocks * 128 * 8));
         CHECK(hipMemcpy(d, h.data(), n_pairs * sizeof(Pair), hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        for (int mode = 0; mode < 3; ++mode) for (int bl : {2048, 1024}) {
+        // 64-byte records: reuse the buffer, a/b fields of record i live at byte 64*i+48
+        for (int mode = 0; mode < 8; ++mode) for (int bl : {2048, 1024}) {
+            if (mode == 3 && bl == 2048) {
+                std::vector<uint32_t> h64((size_t)n_pairs * 16);
+                uint32_t s2 = 777;
+                for (uint32_t i = 0; i < n_pairs; ++i) { for (int k = 0; k < 12; ++k) { float fv = (float)((s2 = s2 * 1664525u + 1013904223u) * 1e-9); memcpy(&h64[(size_t)i * 16 + k], &fv, 4); }
+                    h64[(size_t)i * 16 + 12] = (s2 = s2 * 1664525u + 1013904223u) % n_pairs; h64[(size_t)i * 16 + 13] = 1; h64[(size_t)i * 16 + 14] = h64[(size_t)i * 16 + 15] = 0; }
+                CHECK(hipMemcpy(d, h64.data(), (size_t)n_pairs * 64, hipMemcpyHostToDevice));
+            }
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 CHECK(hipEventRecord(e0));
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 4) hipLaunchKernelGGL((k<3, 32, false>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 5) hipLaunchKernelGGL((k<3, 32, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 6) hipLaunchKernelGGL((k<3, 16, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 7) hipLaunchKernelGGL((k<0, 32, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
             }
-            double visits = (double)bl * 128 * iters;
-            printf("table %7.1f MB mode %d blocks %4d: %8.3f ms  %7.2f Gvisits/s  %7.2f TB/s\n", n_pairs * 128e-6, mode, bl, best, visits / best / 1e6, visits * 128 / best / 1e9);
+            const double frac = mode == 4 || mode == 5 || mode == 7 ? 0.5 : (mode == 6 ? 0.25 : 1.0);
+            double visits = (double)bl * 128 * iters * frac;
+            printf("table %7.1f MB mode %d blocks %4d: %8.3f ms  %7.2f Gvisits/s  %6.2f Gcalls/s\n", n_pairs * (mode >= 3 && mode != 7 ? 64e-6 : 128e-6), mode, bl, best, visits / best / 1e6, (double)bl * 2 * iters / best / 1e6);
         }
         CHECK(hipFree(d)); CHECK(hipFree(out));
     }
