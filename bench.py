@@ -132,6 +132,9 @@ def main():
         alg_bytes = 60.0 * seg + 64.0 * nbox + 72.0 * nprim     # (48 in + 12 out) + 64/box + 72/triangle
         ext_s = agg["extend_ms"] / 1e3
         achieved = alg_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
+        pair_b, prim_b = w.bvh_layout()                         # what the kernel's layout for this scene really reads
+        layout_bytes = 60.0 * seg + 0.5 * pair_b * nbox + prim_b * nprim
+        pmc = pmc_figures()
         out = {
             "metric": "Mrays/s (whole node) dragon PLY BVH; PSNR vs CPU render checked in tests",
             "value": total_rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -148,7 +151,13 @@ def main():
                          "frac": achieved / 8000.0, "traffic": measured_traffic(seg / launches),
                          "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": agg["extend_ms"] / launches,
                          "launches": launches, "bytes_per_segment": alg_bytes / max(seg, 1),
-                         "box_tests_per_segment": nbox / max(seg, 1), "prim_tests_per_segment": nprim / max(seg, 1)},
+                         "box_tests_per_segment": nbox / max(seg, 1), "prim_tests_per_segment": nprim / max(seg, 1),
+                         # the kernel's own layout (f32-lattice pairs / triangles when the scene allows): bytes it requests
+                         "layout": {"pair_bytes": pair_b, "prim_bytes": prim_b, "requested_GBps": layout_bytes / ext_s / 1e9 if ext_s > 0 else 0.0},
+                         # what actually bounds it: divergent 16-B lane accesses at ~1 per clock per CU in the vector L1,
+                         # and VALU issue; figures from the committed PMC passes of the same kernel, not from this run
+                         "lane_accesses_per_clk_per_cu": ((pair_b / 16.0) * 0.5 * nbox + (prim_b / 16.0) * nprim + 6.0 * seg) / ext_s / (256 * 2.4e9) if ext_s > 0 else 0.0,
+                         "pmc": pmc},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, cam_name, a)
@@ -169,6 +178,14 @@ def measured_traffic(segments_per_launch):
         return None
 
 
+def pmc_figures():
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
+        return {k: t[k] for k in ("valu_busy_per_simd", "valu_lane_utilisation", "l2_hit_rate", "wave_wait_fraction", "source") if k in t}
+    except Exception:
+        return None
+
+
 def cpu_baseline(w, cam_name, a):
     """The CPU oracle (a restatement — kind "port" — of the single-threaded reference) timed on this host, 1 core,
     on a bounded sample: the same scene, BVH and camera at 480x270, spp chosen for ~cpu-seconds of work."""
@@ -182,9 +199,14 @@ def cpu_baseline(w, cam_name, a):
     spp = max(1, min(256, int(a.cpu_seconds / max(d1, 1e-3))))
     t = time.perf_counter(); _, c = osc.render(oc, "bvh", 1, spp, a.max_depth, seed=1, nthreads=1); dt = time.perf_counter() - t
     rays = c["primary_rays"] + c["scatter_rays"]
+    # the same oracle with image rows split over host threads — NOT reference behaviour, reported beside it
+    nth = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
+    t = time.perf_counter(); _, c2 = osc.render(oc, "bvh", 1, spp, a.max_depth, seed=1, nthreads=nth); dt2 = time.perf_counter() - t
+    rays2 = c2["primary_rays"] + c2["scatter_rays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"same scene/BVH/camera at 480x{cam.image_height}, {spp} spp, depth {a.max_depth}: {rays} rays in {dt:.1f} s on 1 host core "
-                      f"(host has {os.cpu_count()} logical CPUs; the reference is single-threaded by construction)"}
+                      f"(host has {os.cpu_count()} logical CPUs; the reference is single-threaded by construction)",
+            "all_cores": {"value": rays2 / dt2 / 1e6, "unit": "Mrays/s", "cores": nth, "note": "rows split over std::threads; not reference behaviour"}}
 
 
 if __name__ == "__main__":

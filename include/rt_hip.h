@@ -99,6 +99,11 @@ int rt_scene_set_grid(rt_scene*, const rt_grid_desc*, const double* cell_aabb, c
 enum { RT_OPT_DRAW_BOXES = 1 };
 int rt_scene_set_options(rt_scene*, uint32_t flags);
 
+/* Bytes the BVH extend kernel reads per sibling pair (two box tests) and per primitive test with the layout chosen for
+ * this scene by rt_scene_set_bvh: 128 / 80 in general, 64 / 48 when every coordinate lies on an f32 lattice (PLY meshes:
+ * parser.rs:67-73).  No reference counterpart; bench.py prices the kernel's traffic with it. */
+int rt_scene_bvh_layout(const rt_scene*, uint32_t* pair_bytes, uint32_t* prim_bytes);
+
 /* Parity entry: one `HittableList::hit(r, Interval(tmin,tmax), &mut HitRecord::default(), data)`
  * (hittable_list.rs:65-102) per ray.  orig/dir are n*3 doubles (xyz interleaved).  Any output may be NULL.
  * out_prim: file-order index of the last accepted primitive (-1: none); out_t: rec.t after the call;

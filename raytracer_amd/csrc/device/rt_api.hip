@@ -29,7 +29,7 @@ hipStream_t g_stream = nullptr;
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
 uint32_t g_stream_blocks = 4096;
 uint64_t g_batch_paths = 0;           // paths in flight per batch; 0 = size from free HBM (RT_BATCH_PATHS overrides)
-uint32_t g_tune = (16u << 16) | (1u << 8) | 2u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
+uint32_t g_tune = (8u << 16) | (1u << 8) | 1u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
 unsigned long long* g_dbg = nullptr;  // diagnostic builds (-DRT_STAMPS) only
 int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
@@ -147,10 +147,11 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
             hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
         else {
             BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
-            if (g_compact && sc->lattice_scale > 0.0)
-                hipLaunchKernelGGL(k_extend_bvh2<true>, grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
-            else
-                hipLaunchKernelGGL(k_extend_bvh2<false>, grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg);
+            const bool c32 = g_compact && sc->lattice_scale > 0.0;
+#define RT_LAUNCH_BVH2(C, T) hipLaunchKernelGGL((k_extend_bvh2<C, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg)
+            if (c32) { if (out.trace) RT_LAUNCH_BVH2(true, true); else RT_LAUNCH_BVH2(true, false); }
+            else     { if (out.trace) RT_LAUNCH_BVH2(false, true); else RT_LAUNCH_BVH2(false, false); }
+#undef RT_LAUNCH_BVH2
         }
         break;
     case RT_ALGO_NAIVE:
@@ -362,6 +363,14 @@ int rt_scene_set_options(rt_scene* sc, uint32_t flags) {
     if (!sc) return fail(RT_E_ARG, "null argument");
     if (flags & ~(uint32_t)RT_OPT_DRAW_BOXES) return fail(RT_E_ARG, "unknown option bits 0x%x", flags & ~(uint32_t)RT_OPT_DRAW_BOXES);
     sc->draw_boxes = (flags & RT_OPT_DRAW_BOXES) != 0;
+    return RT_OK;
+}
+
+int rt_scene_bvh_layout(const rt_scene* sc, uint32_t* pair_bytes, uint32_t* prim_bytes) {
+    if (!sc || !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
+    const bool c32 = g_compact && sc->lattice_scale > 0.0 && !sc->draw_boxes && g_extend_variant == 2;
+    if (pair_bytes) *pair_bytes = c32 ? (uint32_t)sizeof(DPair32) : 2u * (uint32_t)sizeof(DNode);
+    if (prim_bytes) *prim_bytes = c32 ? (uint32_t)sizeof(DPrim32) : (uint32_t)sizeof(DPrim);
     return RT_OK;
 }
 

@@ -101,6 +101,8 @@ struct __align__(16) DNode { double mn[3]; double mx[3]; uint32_t a, b, pad0, pa
 // the same lattice).  The device widens and scales with the same two IEEE operations, so every value it computes with is
 // identical to the f64 one — the point is that a divergent 16-byte lane access costs the vector L1 one cycle each, and a
 // sibling pair is then 4 accesses instead of 8, a triangle 3 instead of 6.
+// scale is 100 or 1: an f32 (24 significant bits) times either is exact in f64, so plane - o can also be formed as one
+// fma(f, scale, -o): with an exact product the single rounding of the fma is the rounding of the subtraction.
 //   DPair32: children of one internal node.  a/b as in DNode, except that an internal child's `a` is a pair index.
 struct __align__(16) DPair32 { float box[12]; uint32_t la, lb, ra, rb; };      // box: L.mn, L.mx, R.mn, R.mx
 struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; };          // triangles only
@@ -229,6 +231,30 @@ RT_DEV bool slab_fast(const double* mn, const double* mx, V3 o, V3 inv, double& 
     t0 = (mn[1] - o.y) * inv.y; t1 = (mx[1] - o.y) * inv.y;
     tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
     t0 = (mn[2] - o.z) * inv.z; t1 = (mx[2] - o.z) * inv.z;
+    tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
+    return !(tmax < tmin);
+}
+// The same two tests on precomputed differences dmn = mn - o, dmx = mx - o (the first operation of every axis above)
+RT_DEV bool slab_d(const double* dmn, const double* dmx, V3 inv, double& tmin, double& tmax) {
+    double t0, t1, lo, hi;
+    t0 = dmn[0] * inv.x; t1 = dmx[0] * inv.x;
+    lo = (t0 < t1) ? t0 : t1; hi = (t0 < t1) ? t1 : t0;
+    if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi;
+    t0 = dmn[1] * inv.y; t1 = dmx[1] * inv.y;
+    lo = (t0 < t1) ? t0 : t1; hi = (t0 < t1) ? t1 : t0;
+    if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi;
+    t0 = dmn[2] * inv.z; t1 = dmx[2] * inv.z;
+    lo = (t0 < t1) ? t0 : t1; hi = (t0 < t1) ? t1 : t0;
+    if (lo > tmin) tmin = lo; if (hi < tmax) tmax = hi;
+    return !(tmax < tmin);
+}
+RT_DEV bool slab_fast_d(const double* dmn, const double* dmx, V3 inv, double& tmin, double& tmax) {
+    double t0, t1;
+    t0 = dmn[0] * inv.x; t1 = dmx[0] * inv.x;
+    tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
+    t0 = dmn[1] * inv.y; t1 = dmx[1] * inv.y;
+    tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
+    t0 = dmn[2] * inv.z; t1 = dmx[2] * inv.z;
     tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
     return !(tmax < tmin);
 }

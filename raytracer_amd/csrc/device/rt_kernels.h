@@ -39,7 +39,7 @@ __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, co
                              double tmin0, double tmax0, ExtendOut out, StackEntry* stack, unsigned long long* stats);
 // tree and primitives as the persistent extend kernel reads them; C32 selects the compact lattice forms (rt_device.h)
 struct BvhView { const DNode* nodes; const DPrim* prims; const DPair32* pairs32; const DPrim32* prims32; double scale; };
-template <bool C32>
+template <bool C32, bool TRACE>
 __global__ void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
 __global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,

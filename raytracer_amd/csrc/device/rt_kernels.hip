@@ -138,8 +138,9 @@ __global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, con
 // boolean, and maps the primitive back to its file-order index.
 // `edge` = rec.hits_aabb_edge (draw-boxes only): bit 1 of the trace byte; in render mode it replaces the primitive, because
 // ray_color returns red whether or not anything was hit (camera.rs:162-164,178-180).
+template <int MODE = 2>    // 0: render format, 1: trace format, 2: decided at run time by out.trace;  +4: no tn (single-type scenes)
 RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState& rec, const DPrim* prims, bool edge = false) {
-    if (out.trace) {
+    if ((MODE & 3) == 1 || ((MODE & 3) == 2 && out.trace)) {
         if (out.prim) out.prim[q] = rec.prim >= 0 ? (int32_t)prims[rec.prim].orig : -1;
         if (out.t) out.t[q] = rec.t;
         if (out.tp) out.tp[q] = rec.tp;
@@ -147,7 +148,7 @@ RT_DEV void store_hit(const ExtendOut& out, uint64_t q, bool hit, const HitState
     } else {
         out.prim[q] = edge ? RT_HIT_EDGE : (hit ? rec.prim : -1);
         out.tp[q] = rec.tp;
-        if (out.tn) out.tn[q] = rec.tn;
+        if (!(MODE & 4) && out.tn) out.tn[q] = rec.tn;
     }
 }
 
@@ -252,8 +253,8 @@ template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, co
 // result is identical), restructured for a wave64 machine whose lanes finish at very different times:
 //   * a wave keeps its 64 lanes fed: when enough lanes (tune bits 16..23) are idle it pulls fresh rays for them from the
 //     queue (one atomic per chunk of rays per wave), instead of waiting for its slowest lane;
-//   * one loop iteration = [internal-node visit for every lane] then [leaf tests and stack pops until the lane
-//     stands on an internal node again], so the expensive two-box visit always runs with all live lanes;
+//   * lanes on internal nodes and lanes on leaves / waiting to pop are served by separate phases; the wave votes which
+//     one to run, so each phase's instructions execute with as many lanes as possible;
 //   * the continuation stack's top RT_STK entries live in LDS ([level][lane]: conflict-free for b64 and b32
 //     accesses whatever level each lane is on); deeper entries spill to HBM as stack[level][thread].
 #define RT_STK 8
@@ -274,16 +275,19 @@ RT_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(
 RT_DEV uint32_t popc64(unsigned long long m) { return (uint32_t)__builtin_popcountll(m); }
 
 RT_DEV double lattice(uint32_t f32_bits, double scale) { return (double)__uint_as_float(f32_bits) * scale; }
+// plane - o for a lattice plane: the product is exact (rt_device.h), so the fma rounds exactly as `plane - o` does
+RT_DEV double lattice_minus(uint32_t f32_bits, double scale, double o) { return __builtin_fma((double)__uint_as_float(f32_bits), scale, -o); }
 
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
 #endif
-template <bool C32>
+template <bool C32, bool TRACE>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out,
                                                           StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
                                                           unsigned long long* dbg) {
     RT_STAMP_DECL
+    constexpr int SH_MODE = (TRACE ? 1 : 0) | (C32 ? 4 : 0);
     const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu;
     const uint32_t refill_min = ((tune >> 16) & 0xffu) > 64u ? 64u : ((tune >> 16) & 0xffu);   // a fully idle wave always refills
     __shared__ double s_fd[RT_STK][RT_BLOCK];
@@ -299,8 +303,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     // counters: box tests = 2 per internal visit + 1 per ray (root); traversal steps = internal visits + leaves
     uint32_t c_int = 0, c_leaf = 0, c_prim = 0, c_overlap = 0, c_rays = 0;
 
-    bool active = false, need_pop = false, regular = true, all_regular = true;
-    uint32_t q = 0, cur_a = 0, cur_b = 0, sp = 0, lo = 0;
+    // A lane's state is the `b` word of the node it stands on (no separate flags: every vote is one compare):
+    //   0               on an internal node, cur_a = its children (internal nodes carry b == 0)
+    //   RT_LEAF | k     on a leaf with k >= 1 primitives still to test, cur_a = the next one
+    //   RT_LEAF         nothing left here: pop the continuation stack (a finished leaf counts down to exactly this)
+    //   RT_IDLE         no ray
+    constexpr uint32_t RT_IDLE = 1u, RT_POP = RT_LEAF;
+    bool regular = true, all_regular = true;
+    uint32_t q = 0, cur_a = 0, cur_b = RT_IDLE, sp = 0, lo = 0;
     bool flag = false;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
     double tmax = tmax0;
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
         // ---- refill idle lanes (looked at only after lanes have finished: nothing else changes the idle set)
         RT_STAMP(tk0 = clock64(); ++n_it;)
         if (look_for_rays) {
-            const unsigned long long idle = ballot64(!active);
+            const unsigned long long idle = ballot64(cur_b == RT_IDLE);
             const uint32_t n_idle = popc64(idle);
             if (!exhausted && n_idle >= refill_min) {
                 RT_STAMP(++n_ref;)
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 }
                 const uint32_t avail = c_end - c_next;
                 const uint32_t rank = popc64(idle & ((1ull << lane) - 1ull));
-                if (!active && rank < avail) {
+                if (cur_b == RT_IDLE && rank < avail) {
                     q = c_next + rank;
                     o = v3(in.ox[q], in.oy[q], in.oz[q]);
                     d = v3(in.dx[q], in.dy[q], in.dz[q]);
@@ -335,54 +345,58 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     regular = ray_is_regular(o, inv);
                     rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
                     ++c_rays;
-                    tmax = tmax0; sp = 0; lo = 0; flag = false; need_pop = false;
+                    tmax = tmax0; sp = 0; lo = 0; flag = false;
                     double e0 = tmin0, e1 = tmax0;
-                    if (slab(root.mn, root.mx, o, inv, e0, e1)) { active = true; cur_a = root_a; cur_b = root.b; }   // bvh.rs:84-85
-                    else store_hit(out, q, false, rec, prims);
+                    if (slab(root.mn, root.mx, o, inv, e0, e1)) { cur_a = root_a; cur_b = root.b; }   // bvh.rs:84-85
+                    else store_hit<SH_MODE>(out, q, false, rec, prims);
                 }
                 const uint32_t taken = (n_idle < avail) ? n_idle : avail;
                 c_next += taken;
                 // a chunk that ran out mid-refill leaves lanes idle: look again next iteration (the next chunk is fetched then)
                 look_for_rays = !exhausted && taken < n_idle;
-                all_regular = ballot64(active && !regular) == 0;     // min/max box test is exact only for regular rays
+                all_regular = ballot64(cur_b != RT_IDLE && !regular) == 0;     // min/max box test is exact only for regular rays
                 RT_STAMP(l_ref += taken; tk_ref += clock64() - tk0;)
             } else {
                 look_for_rays = false;
             }
-            if (ballot64(active) == 0) { if (exhausted) break; look_for_rays = true; continue; }
+            if (ballot64(cur_b != RT_IDLE) == 0) { if (exhausted) break; look_for_rays = true; continue; }
         }
 
         // ---- phase vote.  A lane is either on an internal node (wants the two-box visit) or on a leaf / waiting
-        // to pop (wants the primitive tests + stack work).  Running both every iteration leaves most lanes masked
+        // to pop (wants the primitive test + stack work).  Running both every iteration leaves most lanes masked
         // in one of them; instead the wave runs the phase that serves more lanes per instruction and the others wait.
-        const bool want_leaf = active && (need_pop || (cur_b & RT_LEAF));
-        const uint32_t n_leaf = popc64(ballot64(want_leaf));
-        const uint32_t n_int = popc64(ballot64(active && !want_leaf));
-        RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
-        if (n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int)) {   // never starve: one side is non-empty
+        // Internal visits come in runs, so they get a loop of their own: only their own state is carried around it.
+        for (;;) {
+            const uint32_t n_leaf = popc64(ballot64((int32_t)cur_b < 0));
+            const uint32_t n_int = popc64(ballot64(cur_b == 0u));
+            RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
+            if (!(n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int))) break;   // never starve: one side is non-empty
             // ---- one internal-node visit (bvh.rs:203-229), branch-free apart from the push
-            if (active && !want_leaf) {
+            if (cur_b == 0u) {
                 ++c_int;                                 // bvh.rs:190 (and two box tests, bvh.rs:183)
-                struct { double mn[3], mx[3]; uint32_t a, b; } L, R;
+                double dLmn[3], dLmx[3], dRmn[3], dRmx[3];          // box planes minus the ray origin (aabb.rs:36-37)
+                uint32_t La, Lb, Ra, Rb;
                 if (C32) {                               // 64-byte pair: four 16-byte accesses
                     const uint4* pp = (const uint4*)(bvh.pairs32 + cur_a);
                     const uint4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
-                    L.mn[0] = lattice(q0.x, scale); L.mn[1] = lattice(q0.y, scale); L.mn[2] = lattice(q0.z, scale);
-                    L.mx[0] = lattice(q0.w, scale); L.mx[1] = lattice(q1.x, scale); L.mx[2] = lattice(q1.y, scale);
-                    R.mn[0] = lattice(q1.z, scale); R.mn[1] = lattice(q1.w, scale); R.mn[2] = lattice(q2.x, scale);
-                    R.mx[0] = lattice(q2.y, scale); R.mx[1] = lattice(q2.z, scale); R.mx[2] = lattice(q2.w, scale);
-                    L.a = q3.x; L.b = q3.y; R.a = q3.z; R.b = q3.w;
+                    dLmn[0] = lattice_minus(q0.x, scale, o.x); dLmn[1] = lattice_minus(q0.y, scale, o.y); dLmn[2] = lattice_minus(q0.z, scale, o.z);
+                    dLmx[0] = lattice_minus(q0.w, scale, o.x); dLmx[1] = lattice_minus(q1.x, scale, o.y); dLmx[2] = lattice_minus(q1.y, scale, o.z);
+                    dRmn[0] = lattice_minus(q1.z, scale, o.x); dRmn[1] = lattice_minus(q1.w, scale, o.y); dRmn[2] = lattice_minus(q2.x, scale, o.z);
+                    dRmx[0] = lattice_minus(q2.y, scale, o.x); dRmx[1] = lattice_minus(q2.z, scale, o.y); dRmx[2] = lattice_minus(q2.w, scale, o.z);
+                    La = q3.x; Lb = q3.y; Ra = q3.z; Rb = q3.w;
                 } else {                                 // siblings are adjacent: one 128-byte fetch, eight accesses
                     const DNode* pair = nodes + cur_a;
                     const DNode l = pair[0], r = pair[1];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { L.mn[c] = l.mn[c]; L.mx[c] = l.mx[c]; R.mn[c] = r.mn[c]; R.mx[c] = r.mx[c]; }
-                    L.a = l.a; L.b = l.b; R.a = r.a; R.b = r.b;
+                    dLmn[0] = l.mn[0] - o.x; dLmn[1] = l.mn[1] - o.y; dLmn[2] = l.mn[2] - o.z;
+                    dLmx[0] = l.mx[0] - o.x; dLmx[1] = l.mx[1] - o.y; dLmx[2] = l.mx[2] - o.z;
+                    dRmn[0] = r.mn[0] - o.x; dRmn[1] = r.mn[1] - o.y; dRmn[2] = r.mn[2] - o.z;
+                    dRmx[0] = r.mx[0] - o.x; dRmx[1] = r.mx[1] - o.y; dRmx[2] = r.mx[2] - o.z;
+                    La = l.a; Lb = l.b; Ra = r.a; Rb = r.b;
                 }
                 double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
                 bool lh, rh;
-                if (all_regular) { lh = slab_fast(L.mn, L.mx, o, inv, ld, lx); rh = slab_fast(R.mn, R.mx, o, inv, rd, rx); }
-                else { lh = slab(L.mn, L.mx, o, inv, ld, lx); rh = slab(R.mn, R.mx, o, inv, rd, rx); }
+                if (all_regular) { lh = slab_fast_d(dLmn, dLmx, inv, ld, lx); rh = slab_fast_d(dRmn, dRmx, inv, rd, rx); }
+                else { lh = slab_d(dLmn, dLmx, inv, ld, lx); rh = slab_d(dRmn, dRmx, inv, rd, rx); }
                 const bool both = lh && rh;
                 const bool go_right = both ? (ld >= rd) : rh;      // bvh.rs:210-211 (tie -> right is `close`), :226-227
                 if (both) {
@@ -393,60 +407,61 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     }
                     const uint32_t s = sp & (RT_STK - 1);
                     s_fd[s][tx] = ld >= rd ? ld : rd;    // bvh.rs:212 f64::max of two non-NaN values
-                    s_ab[s][tx] = make_uint2(go_right ? L.a : R.a, (go_right ? L.b : R.b) | (flag ? 0x40000000u : 0u));
+                    s_ab[s][tx] = make_uint2(go_right ? La : Ra, (go_right ? Lb : Rb) | (flag ? 0x40000000u : 0u));
                     ++sp; flag = false;
                 }
-                cur_a = go_right ? R.a : L.a; cur_b = go_right ? R.b : L.b;
-                need_pop = !(lh || rh);
+                cur_a = go_right ? Ra : La;
+                cur_b = (lh || rh) ? (go_right ? Rb : Lb) : RT_POP;
             }
             RT_STAMP(++n_intp; l_int += n_int; tk_int += clock64() - tk0;)
-        } else {
-            // ---- one primitive test of the leaf (bvh.rs:195-202), then pops until the lane has a node again or its
-            // ray is finished.  One primitive per call: 96 % of the leaves hold one primitive, and a lane that has more
-            // keeps its place (cur_a / count in cur_b advance) and joins the next leaf phase instead of making the wave loop.
-            // closest_so_far of the leaf (bvh.rs:193,200) lives in tmax: once a primitive is accepted the frame's old
-            // tmax is dead (every later entry into a node goes through a pop with close_hit set, which reloads it).
-            bool done = false;
-            if (want_leaf) {
-                if (!need_pop) {
-                    ++c_prim;
-                    bool acc;
-                    if (C32) {                           // 48-byte triangle: three 16-byte accesses
-                        const uint4* tp = (const uint4*)(bvh.prims32 + cur_a);
-                        const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                        DPrim P;
-                        P.v[0] = lattice(q0.x, scale); P.v[1] = lattice(q0.y, scale); P.v[2] = lattice(q0.z, scale);
-                        P.v[3] = lattice(q0.w, scale); P.v[4] = lattice(q1.x, scale); P.v[5] = lattice(q1.y, scale);
-                        P.v[6] = lattice(q1.z, scale); P.v[7] = lattice(q1.w, scale); P.v[8] = lattice(q2.x, scale);
-                        acc = hit_triangle_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
-                    } else {
-                        const DPrim P = prims[cur_a];
-                        acc = hit_prim_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
-                    }
-                    flag = flag || acc; tmax = acc ? rec.t : tmax;
-                    ++cur_a; --cur_b;                    // leaves hold >= 1 primitive (checked by rt_scene_set_bvh)
-                    need_pop = (cur_b & 0x3fffffffu) == 0;
-                    c_leaf += need_pop ? 1u : 0u;        // bvh.rs:190, once per leaf
-                }
-                while (need_pop) {
-                    if (sp == 0) { done = true; need_pop = false; }
-                    else {
-                        --sp;
-                        const uint32_t s = sp & (RT_STK - 1);
-                        double far_d = s_fd[s][tx]; uint2 ab = s_ab[s][tx];
-                        if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ab.x = e.a; ab.y = e.b; }
-                        const bool close_hit = flag;
-                        flag = flag || ((ab.y >> 30) & 1u);
-                        const bool overlap = close_hit && far_d < rec.t;      // bvh.rs:213-222
-                        if (overlap) { ++c_overlap; tmax = rec.t; }
-                        if (overlap || !close_hit) { cur_a = ab.x; cur_b = ab.y & ~0x40000000u; need_pop = false; }   // :219 / :223
-                    }
-                }
-                if (done) { store_hit(out, q, rec.prim >= 0, rec, prims); active = false; }
-            }
-            look_for_rays = ballot64(done) != 0;
-            RT_STAMP(++n_leafp; l_leaf += n_leaf; tk_leaf += clock64() - tk0;)
         }
+
+        // ---- one primitive test of the leaf (bvh.rs:195-202), then pops until the lane has a node again or its
+        // ray is finished.  One primitive per call: 96 % of the leaves hold one primitive, and a lane that has more
+        // keeps its place (cur_a / count in cur_b advance) and joins the next leaf phase instead of making the wave loop.
+        // closest_so_far of the leaf (bvh.rs:193,200) lives in tmax: once a primitive is accepted the frame's old
+        // tmax is dead (every later entry into a node goes through a pop with close_hit set, which reloads it).
+        bool done = false;
+        RT_STAMP(const uint32_t st_leaf = popc64(ballot64((int32_t)cur_b < 0)); tk0 = clock64();)
+        if ((int32_t)cur_b < 0) {
+            if (cur_b != RT_POP) {
+                ++c_prim;
+                bool acc;
+                if (C32) {                           // 48-byte triangle: three 16-byte accesses
+                    const uint4* tp = (const uint4*)(bvh.prims32 + cur_a);
+                    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    DPrim P;
+                    P.v[0] = lattice(q0.x, scale); P.v[1] = lattice(q0.y, scale); P.v[2] = lattice(q0.z, scale);
+                    P.v[3] = lattice(q0.w, scale); P.v[4] = lattice(q1.x, scale); P.v[5] = lattice(q1.y, scale);
+                    P.v[6] = lattice(q1.z, scale); P.v[7] = lattice(q1.w, scale); P.v[8] = lattice(q2.x, scale);
+                    acc = hit_triangle_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
+                } else {
+                    const DPrim P = prims[cur_a];
+                    acc = hit_prim_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
+                }
+                flag = flag || acc; tmax = acc ? rec.t : tmax;
+                ++cur_a; --cur_b;                    // leaves hold >= 1 primitive (checked by rt_scene_set_bvh)
+                c_leaf += (cur_b == RT_POP) ? 1u : 0u;   // bvh.rs:190, once per leaf
+            }
+            while (cur_b == RT_POP) {
+                if (sp == 0) { done = true; cur_b = RT_IDLE; }
+                else {
+                    --sp;
+                    const uint32_t s = sp & (RT_STK - 1);
+                    double far_d = s_fd[s][tx]; uint2 ab = s_ab[s][tx];
+                    asm volatile("" : "+v"(far_d), "+v"(ab.x), "+v"(ab.y));      // keep these as LDS reads (not a flat load of a selected pointer)
+                    if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ab.x = e.a; ab.y = e.b; }
+                    const bool close_hit = flag;
+                    flag = flag || ((ab.y >> 30) & 1u);
+                    const bool overlap = close_hit && far_d < rec.t;      // bvh.rs:213-222
+                    if (overlap) { ++c_overlap; tmax = rec.t; }
+                    if (overlap || !close_hit) { cur_a = ab.x; cur_b = ab.y & ~0x40000000u; }   // :219 / :223
+                }
+            }
+            if (done) store_hit<SH_MODE>(out, q, rec.prim >= 0, rec, prims);
+        }
+        look_for_rays = ballot64(done) != 0;
+        RT_STAMP(++n_leafp; l_leaf += st_leaf; tk_leaf += clock64() - tk0;)
     }
 #ifdef RT_STAMPS
     if (dbg && lane == 0) {
@@ -459,8 +474,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
         stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
-template __global__ void k_extend_bvh2<false>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
-template __global__ void k_extend_bvh2<true>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
+#define RT_INST_BVH2(C, T) template __global__ void k_extend_bvh2<C, T>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
+RT_INST_BVH2(false, false) RT_INST_BVH2(false, true) RT_INST_BVH2(true, false) RT_INST_BVH2(true, true)
 
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, uint32_t n_prims,

@@ -200,6 +200,12 @@ class HittableList:
                                         prim.ctypes.data, t.ctypes.data, tp.ctypes.data, hit.ctypes.data, C.byref(st)))
         return {"prim": prim, "t": t, "tp": tp, "hit": (hit & 1).astype(bool), "edge": (hit & 2).astype(bool), "stats": st.as_dict()}
 
+    def bvh_layout(self):
+        """(bytes per sibling pair, bytes per primitive) the BVH extend kernel reads for this scene."""
+        a, b = C.c_uint32(), C.c_uint32()
+        _hip_check(F.hip_lib().rt_scene_bvh_layout(self._dev, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def close(self):
         if self._dev is not None:
             F.hip_lib().rt_scene_destroy(self._dev)
