@@ -208,3 +208,67 @@ def test_reference_form_extend_kernel_agrees(gpu, monkeypatch):
         monkeypatch.setenv("RT_EXTEND_VARIANT", "2"); rt.init(0)
     assert_trace_equal(w.hit(ro, rd), ref, "variant 2")
     w.close()
+
+
+def test_compact_lattice_layout_is_chosen_for_ply_and_is_bit_identical(gpu, monkeypatch):
+    """PLY coordinates lie on the (f64)f32*100 lattice (parser.rs:67-73), so rt_scene_set_bvh picks the 64-B pair /
+    48-B triangle forms; RT_COMPACT=0 forces the f64 forms.  Same bits either way, and both equal the oracle."""
+    import raytracer_amd as rt
+    w = load_world("dragon_res4")
+    osc = setup_pair(w, "bvh", "sah-position", oracle_own_build=False)
+    ro, rd = random_rays(40000, 21, -15.0, 25.0)
+    ref = osc.trace("bvh", ro, rd)
+    try:
+        monkeypatch.setenv("RT_COMPACT", "0"); rt.init(0); w.upload()
+        assert w.bvh_layout() == (128, 80)
+        plain = w.hit(ro, rd)
+    finally:
+        monkeypatch.setenv("RT_COMPACT", "1"); rt.init(0)
+    w.upload()
+    assert w.bvh_layout() == (64, 48)
+    compact = w.hit(ro, rd)
+    assert_trace_equal(plain, ref, "f64 layout")
+    assert_trace_equal(compact, ref, "compact layout")
+    w.close()
+    # JSON scenes carry arbitrary f64 coordinates: no lattice, generic layout
+    j = load_world("weekend-5-80-15"); j.algorithm = "bvh"; j.init(); j.upload()
+    assert j.bvh_layout() == (128, 80)
+    j.close()
+
+
+def test_subdivided_ply_stays_on_the_lattice_and_matches_oracle(gpu):
+    """The synthetic stand-in for the absent full dragon (bench.py): res4 split twice; midpoints are rounded onto the
+    PLY lattice so the compact layout applies; hits are bit-exact against the oracle on the same mesh."""
+    from raytracer_amd import HittableList
+    w = HittableList.from_ply("scenes/dragon_recon/dragon_vrip_res4.ply", subdivide=1)
+    assert len(w) == 4 * 11102
+    v = w.prims()["v"]
+    f = (v / 100.0).astype(np.float32)
+    assert np.array_equal(f.astype(np.float64) * 100.0, v), "subdivision left the f32*100 lattice"
+    osc = setup_pair(w, "bvh", "sah-position", oracle_own_build=False)
+    w.upload()
+    assert w.bvh_layout() == (64, 48)
+    cam = Camera(w.filename, image_width=256)
+    o, d = cam.get_rays(*primary_rays(cam), sample=0, seed=3)
+    assert_trace_equal(w.hit(o, d), osc.trace("bvh", o, d), "subdivided res4 primary")
+    w.close()
+
+
+def test_lattice_scale_one_and_f32_exact_json_like_scene(gpu):
+    """Coordinates that are f32-exact but not multiples of the PLY scale select the S = 1 lattice."""
+    from raytracer_amd import HittableList
+    rng = np.random.default_rng(4)
+    n = 300
+    v = rng.uniform(-8, 8, size=(n, 9)).astype(np.float32).astype(np.float64)
+    v[:, 3:6] = (v[:, 0:3] + rng.uniform(-1, 1, size=(n, 3))).astype(np.float32)
+    v[:, 6:9] = (v[:, 0:3] + rng.uniform(-1, 1, size=(n, 3))).astype(np.float32)
+    prims = np.zeros(n, dtype=O.PRIM_DT); prims["type"] = 1; prims["v"] = v
+    cent = (v[:, 0:3] + v[:, 3:6] + v[:, 6:9]) / 3.0
+    mats = np.zeros(1, dtype=O.MAT_DT); mats["albedo"] = 0.5
+    w = HittableList.from_arrays(prims, cent, mats, "scenes/none.json")
+    osc = setup_pair(w, "bvh", "sah-position")
+    w.upload()
+    assert w.bvh_layout() == (64, 48)
+    ro, rd = random_rays(20000, 8, -10.0, 10.0)
+    assert_trace_equal(w.hit(ro, rd), osc.trace("bvh", ro, rd), "S=1 lattice")
+    w.close()
