@@ -100,8 +100,8 @@ enum { RT_OPT_DRAW_BOXES = 1 };
 int rt_scene_set_options(rt_scene*, uint32_t flags);
 
 /* Bytes the BVH extend kernel reads per sibling pair (two box tests) and per primitive test with the layout chosen for
- * this scene by rt_scene_set_bvh: 128 / 80 in general, 64 / 48 when every coordinate lies on an f32 lattice (PLY meshes:
- * parser.rs:67-73).  No reference counterpart; bench.py prices the kernel's traffic with it. */
+ * this scene by rt_scene_set_bvh: 112 / 80 in general, 112 / 48 for all-sphere scenes, 64 / 48 when every coordinate lies on
+ * an f32 lattice (PLY meshes: parser.rs:67-73).  No reference counterpart; bench.py prices the kernel's traffic with it. */
 int rt_scene_bvh_layout(const rt_scene*, uint32_t* pair_bytes, uint32_t* prim_bytes);
 
 /* Parity entry: one `HittableList::hit(r, Interval(tmin,tmax), &mut HitRecord::default(), data)`

@@ -89,6 +89,7 @@ struct rt_scene {
     bool bvh_empty_leaf = false;       // a leaf without primitives (only the root of an empty scene): plain kernel only
     DNode* d_nodes = nullptr; DPrim* d_prims_bvh = nullptr; StackEntry* d_stack = nullptr;
     DPair32* d_pairs32 = nullptr; DPrim32* d_prims32 = nullptr; double lattice_scale = 0.0;   // compact forms; scale 0 = not available
+    DPair64* d_pairs64 = nullptr; DSphere* d_spheres = nullptr;                               // generic pairs; spheres only for all-sphere scenes
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     // grid
     bool have_grid = false; DGrid grid{};
@@ -146,11 +147,13 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         else if (g_extend_variant == 1 || sc->bvh_empty_leaf)
             hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
         else {
-            BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
-            const bool c32 = g_compact && sc->lattice_scale > 0.0;
-#define RT_LAUNCH_BVH2(C, T) hipLaunchKernelGGL((k_extend_bvh2<C, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg)
-            if (c32) { if (out.trace) RT_LAUNCH_BVH2(true, true); else RT_LAUNCH_BVH2(true, false); }
-            else     { if (out.trace) RT_LAUNCH_BVH2(false, true); else RT_LAUNCH_BVH2(false, false); }
+            BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs64 = sc->d_pairs64; v.spheres = sc->d_spheres;
+            v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
+            const bool c32 = g_compact && sc->lattice_scale > 0.0, sph = g_compact && sc->d_spheres != nullptr;
+#define RT_LAUNCH_BVH2(N, P, T) hipLaunchKernelGGL((k_extend_bvh2<N, P, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg)
+            if (c32)      { if (out.trace) RT_LAUNCH_BVH2(1, 1, true); else RT_LAUNCH_BVH2(1, 1, false); }
+            else if (sph) { if (out.trace) RT_LAUNCH_BVH2(0, 2, true); else RT_LAUNCH_BVH2(0, 2, false); }
+            else          { if (out.trace) RT_LAUNCH_BVH2(0, 0, true); else RT_LAUNCH_BVH2(0, 0, false); }
 #undef RT_LAUNCH_BVH2
         }
         break;
@@ -354,6 +357,7 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->d_prims) (void)hipFree(sc->d_prims); if (sc->d_mats) (void)hipFree(sc->d_mats);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
     if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
+    if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
     sc->ws.release();
     delete sc;
@@ -368,9 +372,10 @@ int rt_scene_set_options(rt_scene* sc, uint32_t flags) {
 
 int rt_scene_bvh_layout(const rt_scene* sc, uint32_t* pair_bytes, uint32_t* prim_bytes) {
     if (!sc || !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
-    const bool c32 = g_compact && sc->lattice_scale > 0.0 && !sc->draw_boxes && g_extend_variant == 2;
-    if (pair_bytes) *pair_bytes = c32 ? (uint32_t)sizeof(DPair32) : 2u * (uint32_t)sizeof(DNode);
-    if (prim_bytes) *prim_bytes = c32 ? (uint32_t)sizeof(DPrim32) : (uint32_t)sizeof(DPrim);
+    const bool persistent = !sc->draw_boxes && g_extend_variant == 2 && !sc->bvh_empty_leaf;
+    const bool c32 = persistent && g_compact && sc->lattice_scale > 0.0, sph = persistent && g_compact && sc->d_spheres != nullptr;
+    if (pair_bytes) *pair_bytes = c32 ? (uint32_t)sizeof(DPair32) : (persistent ? (uint32_t)sizeof(DPair64) : 2u * (uint32_t)sizeof(DNode));
+    if (prim_bytes) *prim_bytes = c32 ? (uint32_t)sizeof(DPrim32) : (sph ? (uint32_t)sizeof(DSphere) : (uint32_t)sizeof(DPrim));
     return RT_OK;
 }
 
@@ -411,12 +416,43 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     for (uint32_t k = 0; k < n; ++k) dp[k] = to_dprim(sc->h_prims[prim_index[k]], prim_index[k]);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
     if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
+    if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres);
+    sc->d_pairs64 = nullptr; sc->d_spheres = nullptr;
     sc->d_nodes = nullptr; sc->d_prims_bvh = nullptr; sc->d_stack = nullptr; sc->d_pairs32 = nullptr; sc->d_prims32 = nullptr; sc->lattice_scale = 0.0; sc->have_bvh = false;
     HIPCHECK(hipMalloc(&sc->d_nodes, dn.size() * sizeof(DNode)));
     HIPCHECK(hipMalloc(&sc->d_prims_bvh, dp.size() * sizeof(DPrim)));
     HIPCHECK(hipMalloc(&sc->d_stack, (size_t)depth * g_extend_blocks * RT_BLOCK * sizeof(StackEntry)));
     HIPCHECK(hipMemcpy(sc->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(sc->d_prims_bvh, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    // generic sibling pairs (112 B) and, for all-sphere scenes, 48-B spheres
+    {
+        std::vector<DPair64> pairs(((size_t)n_nodes + 2) / 2);
+        for (auto& pr : pairs) memset(&pr, 0, sizeof pr);
+        for (size_t p = 0; p < pairs.size(); ++p)
+            for (int side = 0; side < 2; ++side) {
+                const size_t di = 2 * p + side;
+                if (di == 0 || di > n_nodes) continue;
+                const DNode& nd = dn[di];
+                double* box = pairs[p].box + 6 * side;
+                for (int c = 0; c < 3; ++c) { box[c] = nd.mn[c]; box[3 + c] = nd.mx[c]; }
+                const uint32_t a = (nd.b & RT_LEAF) ? nd.a : nd.a >> 1;
+                if (side == 0) { pairs[p].la = a; pairs[p].lb = nd.b; } else { pairs[p].ra = a; pairs[p].rb = nd.b; }
+            }
+        HIPCHECK(hipMalloc(&sc->d_pairs64, pairs.size() * sizeof(DPair64)));
+        HIPCHECK(hipMemcpy(sc->d_pairs64, pairs.data(), pairs.size() * sizeof(DPair64), hipMemcpyHostToDevice));
+        bool all_spheres = n > 0;
+        for (uint32_t k = 0; all_spheres && k < n; ++k) all_spheres = sc->h_prims[prim_index[k]].type == RT_SPHERE;
+        if (all_spheres) {
+            std::vector<DSphere> sp(n);
+            for (uint32_t k = 0; k < n; ++k) {
+                const rt_prim& t = sc->h_prims[prim_index[k]];
+                sp[k].c[0] = t.v[0]; sp[k].c[1] = t.v[1]; sp[k].c[2] = t.v[2]; sp[k].r = t.v[3];
+                sp[k].tm = dp[k].tm; sp[k].orig = dp[k].orig; sp[k].pad0 = sp[k].pad1 = 0;
+            }
+            HIPCHECK(hipMalloc(&sc->d_spheres, sp.size() * sizeof(DSphere)));
+            HIPCHECK(hipMemcpy(sc->d_spheres, sp.data(), sp.size() * sizeof(DSphere), hipMemcpyHostToDevice));
+        }
+    }
     // compact forms: all triangles, and every box plane and vertex coordinate on one f32 lattice (scale 100 = PLY, or 1)
     for (double S : {100.0, 1.0}) {
         bool ok = n > 0 && !empty_leaf;

@@ -104,6 +104,10 @@ struct __align__(16) DNode { double mn[3]; double mx[3]; uint32_t a, b, pad0, pa
 // scale is 100 or 1: an f32 (24 significant bits) times either is exact in f64, so plane - o can also be formed as one
 // fma(f, scale, -o): with an exact product the single rounding of the fma is the rounding of the subtraction.
 //   DPair32: children of one internal node.  a/b as in DNode, except that an internal child's `a` is a pair index.
+//   DPair64: the same pair with f64 planes for scenes off the lattice: 112 B = 7 accesses (two 64-B DNodes would be 8)
+//   DSphere: 48-B sphere for all-sphere scenes (3 accesses; the generic 80-B DPrim is 5)
+struct __align__(16) DPair64 { double box[12]; uint32_t la, lb, ra, rb; };     // box: L.mn, L.mx, R.mn, R.mx
+struct __align__(16) DSphere { double c[3]; double r; uint32_t tm, orig, pad0, pad1; };
 struct __align__(16) DPair32 { float box[12]; uint32_t la, lb, ra, rb; };      // box: L.mn, L.mx, R.mn, R.mx
 struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; };          // triangles only
 

@@ -281,13 +281,13 @@ RT_DEV double lattice_minus(uint32_t f32_bits, double scale, double o) { return 
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
 #endif
-template <bool C32, bool TRACE>
+template <int NODES, int PRIMS, bool TRACE>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out,
                                                           StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
                                                           unsigned long long* dbg) {
     RT_STAMP_DECL
-    constexpr int SH_MODE = (TRACE ? 1 : 0) | (C32 ? 4 : 0);
+    constexpr int SH_MODE = (TRACE ? 1 : 0) | (PRIMS != 0 ? 4 : 0);      // single-type scenes never read rec.tn
     const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu;
     const uint32_t refill_min = ((tune >> 16) & 0xffu) > 64u ? 64u : ((tune >> 16) & 0xffu);   // a fully idle wave always refills
     __shared__ double s_fd[RT_STK][RT_BLOCK];
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
     const DNode* __restrict__ nodes = bvh.nodes; const DPrim* __restrict__ prims = bvh.prims;
     const DNode root = nodes[1];                 // device node i+1 = host node i (pairs 128-byte aligned)
-    const uint32_t root_a = (C32 && !(root.b & RT_LEAF)) ? root.a >> 1 : root.a;
+    const uint32_t root_a = (root.b & RT_LEAF) ? root.a : root.a >> 1;       // internal: index of its children's pair
     const double scale = bvh.scale;
 
     for (;;) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 ++c_int;                                 // bvh.rs:190 (and two box tests, bvh.rs:183)
                 double dLmn[3], dLmx[3], dRmn[3], dRmx[3];          // box planes minus the ray origin (aabb.rs:36-37)
                 uint32_t La, Lb, Ra, Rb;
-                if (C32) {                               // 64-byte pair: four 16-byte accesses
+                if (NODES == 1) {                        // 64-byte pair: four 16-byte accesses
                     const uint4* pp = (const uint4*)(bvh.pairs32 + cur_a);
                     const uint4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
                     dLmn[0] = lattice_minus(q0.x, scale, o.x); dLmn[1] = lattice_minus(q0.y, scale, o.y); dLmn[2] = lattice_minus(q0.z, scale, o.z);
@@ -384,14 +384,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     dRmn[0] = lattice_minus(q1.z, scale, o.x); dRmn[1] = lattice_minus(q1.w, scale, o.y); dRmn[2] = lattice_minus(q2.x, scale, o.z);
                     dRmx[0] = lattice_minus(q2.y, scale, o.x); dRmx[1] = lattice_minus(q2.z, scale, o.y); dRmx[2] = lattice_minus(q2.w, scale, o.z);
                     La = q3.x; Lb = q3.y; Ra = q3.z; Rb = q3.w;
-                } else {                                 // siblings are adjacent: one 128-byte fetch, eight accesses
-                    const DNode* pair = nodes + cur_a;
-                    const DNode l = pair[0], r = pair[1];
-                    dLmn[0] = l.mn[0] - o.x; dLmn[1] = l.mn[1] - o.y; dLmn[2] = l.mn[2] - o.z;
-                    dLmx[0] = l.mx[0] - o.x; dLmx[1] = l.mx[1] - o.y; dLmx[2] = l.mx[2] - o.z;
-                    dRmn[0] = r.mn[0] - o.x; dRmn[1] = r.mn[1] - o.y; dRmn[2] = r.mn[2] - o.z;
-                    dRmx[0] = r.mx[0] - o.x; dRmx[1] = r.mx[1] - o.y; dRmx[2] = r.mx[2] - o.z;
-                    La = l.a; Lb = l.b; Ra = r.a; Rb = r.b;
+                } else {                                 // 112-byte pair: seven accesses
+                    const double2* pp = (const double2*)(bvh.pairs64 + cur_a);
+                    const double2 b0 = pp[0], b1 = pp[1], b2 = pp[2], b3 = pp[3], b4 = pp[4], b5 = pp[5];
+                    const uint4 m = *(const uint4*)(pp + 6);
+                    dLmn[0] = b0.x - o.x; dLmn[1] = b0.y - o.y; dLmn[2] = b1.x - o.z;
+                    dLmx[0] = b1.y - o.x; dLmx[1] = b2.x - o.y; dLmx[2] = b2.y - o.z;
+                    dRmn[0] = b3.x - o.x; dRmn[1] = b3.y - o.y; dRmn[2] = b4.x - o.z;
+                    dRmx[0] = b4.y - o.x; dRmx[1] = b5.x - o.y; dRmx[2] = b5.y - o.z;
+                    La = m.x; Lb = m.y; Ra = m.z; Rb = m.w;
                 }
                 double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
                 bool lh, rh;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
             if (cur_b != RT_POP) {
                 ++c_prim;
                 bool acc;
-                if (C32) {                           // 48-byte triangle: three 16-byte accesses
+                if (PRIMS == 1) {                    // 48-byte triangle: three 16-byte accesses
                     const uint4* tp = (const uint4*)(bvh.prims32 + cur_a);
                     const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                     DPrim P;
@@ -435,8 +436,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     P.v[3] = lattice(q0.w, scale); P.v[4] = lattice(q1.x, scale); P.v[5] = lattice(q1.y, scale);
                     P.v[6] = lattice(q1.z, scale); P.v[7] = lattice(q1.w, scale); P.v[8] = lattice(q2.x, scale);
                     acc = hit_triangle_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
-                } else {
-                    const DPrim P = prims[cur_a];
+                } else if (PRIMS == 2) {             // 48-byte sphere: three accesses (the third only for parity of layout)
+                    const double2* sp2 = (const double2*)(bvh.spheres + cur_a);
+                    const double2 c0 = sp2[0], c1 = sp2[1];
+                    DPrim P; P.v[0] = c0.x; P.v[1] = c0.y; P.v[2] = c1.x; P.v[3] = c1.y;
+                    acc = hit_sphere(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
+                } else {                             // 80-byte primitive: five accesses
+                    const double2* gp = (const double2*)(prims + cur_a);
+                    const double2 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3];
+                    const uint4 g4 = *(const uint4*)(gp + 4);
+                    DPrim P; P.v[0] = g0.x; P.v[1] = g0.y; P.v[2] = g1.x; P.v[3] = g1.y; P.v[4] = g2.x; P.v[5] = g2.y; P.v[6] = g3.x; P.v[7] = g3.y;
+                    P.v[8] = __hiloint2double((int)g4.y, (int)g4.x); P.tm = g4.z; P.orig = g4.w;
                     acc = hit_prim_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
                 }
                 flag = flag || acc; tmax = acc ? rec.t : tmax;
@@ -474,8 +484,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
         stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
-#define RT_INST_BVH2(C, T) template __global__ void k_extend_bvh2<C, T>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
-RT_INST_BVH2(false, false) RT_INST_BVH2(false, true) RT_INST_BVH2(true, false) RT_INST_BVH2(true, true)
+#define RT_INST_BVH2(N, P, T) template __global__ void k_extend_bvh2<N, P, T>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
+RT_INST_BVH2(0, 0, false) RT_INST_BVH2(0, 0, true) RT_INST_BVH2(0, 2, false) RT_INST_BVH2(0, 2, true) RT_INST_BVH2(1, 1, false) RT_INST_BVH2(1, 1, true)
 
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, uint32_t n_prims,

@@ -220,7 +220,7 @@ def test_compact_lattice_layout_is_chosen_for_ply_and_is_bit_identical(gpu, monk
     ref = osc.trace("bvh", ro, rd)
     try:
         monkeypatch.setenv("RT_COMPACT", "0"); rt.init(0); w.upload()
-        assert w.bvh_layout() == (128, 80)
+        assert w.bvh_layout() == (112, 80)
         plain = w.hit(ro, rd)
     finally:
         monkeypatch.setenv("RT_COMPACT", "1"); rt.init(0)
@@ -230,10 +230,13 @@ def test_compact_lattice_layout_is_chosen_for_ply_and_is_bit_identical(gpu, monk
     assert_trace_equal(plain, ref, "f64 layout")
     assert_trace_equal(compact, ref, "compact layout")
     w.close()
-    # JSON scenes carry arbitrary f64 coordinates: no lattice, generic layout
+    # JSON scenes carry arbitrary f64 coordinates: no lattice; f64 pairs (112 B), 48-B spheres when there is nothing else
     j = load_world("weekend-5-80-15"); j.algorithm = "bvh"; j.init(); j.upload()
-    assert j.bvh_layout() == (128, 80)
+    assert j.bvh_layout() == (112, 48)
     j.close()
+    m = weekend_mixed(); m.algorithm = "bvh"; m.init(); m.upload()
+    assert m.bvh_layout() == (112, 80)
+    m.close()
 
 
 def test_subdivided_ply_stays_on_the_lattice_and_matches_oracle(gpu):
