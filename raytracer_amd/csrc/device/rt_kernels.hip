@@ -689,13 +689,17 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
                 DMat m = mats[P.tm & 0x7fffffffu];
                 Rng g(seed, id % WH, s_base + id / WH, 1u + bounce);
                 V3 attenuation; bool scattered;
+                // Lambertian and Metal both start with Vec3::random_unit() (material.rs:36,69): one rejection loop for the
+                // lanes of both, instead of one loop per material branch (the wave pays a loop's longest lane each time)
+                V3 ru = v3(0, 0, 0);
+                if (m.type != 2) ru = random_unit(g);
                 if (m.type == 0) {                                    // Lambertian material.rs:35-46
-                    V3 sd = normal + random_unit(g);
+                    V3 sd = normal + ru;
                     if (near_zero(sd)) sd = normal;
                     nd = sd; attenuation = v3(m.albedo[0], m.albedo[1], m.albedo[2]); scattered = true;
                 } else if (m.type == 1) {                             // Metal material.rs:67-74
                     V3 reflected = reflect(d, normal);
-                    reflected = unit(reflected) + (m.param * random_unit(g));
+                    reflected = unit(reflected) + (m.param * ru);
                     nd = reflected; attenuation = v3(m.albedo[0], m.albedo[1], m.albedo[2]);
                     scattered = dot(nd, normal) > 0.0;
                 } else {                                              // Dielectric material.rs:94-113
