@@ -25,6 +25,7 @@ static const char* kHelp =
     "      --spp <N>                Samples per pixel [default: 50] (addition; main.rs:75)\n"
     "      --max-depth <N>          Bounce limit [default: 50]   (addition; main.rs:76)\n"
     "      --seed <N>               Seed of the counter RNG [default: 1] (addition)\n"
+    "      --binary-ppm             Write the image as binary PPM (P6) instead of P3 text (addition)\n"
     "      --device <N>             GPU index [default: 0] (addition)\n"
     "      --subdivide <L>          Split every PLY triangle into 4, L times (addition; synthetic meshes)\n"
     "      --output-dir <DIR>       Where the .ppm and stats.csv go [default: output]\n"
@@ -59,6 +60,7 @@ bool parse_cli(int argc, const char* const* argv, Cli& out, std::string& err) {
         else if (key == "--seed") { if (!need(i, "--seed", v)) return false; out.seed = strtoull(v.c_str(), nullptr, 10); }
         else if (key == "--device") { if (!need(i, "--device", v)) return false; out.device = atoi(v.c_str()); }
         else if (key == "--subdivide") { if (!need(i, "--subdivide", v)) return false; out.subdivide = atoi(v.c_str()); if (out.subdivide < 0 || out.subdivide > 4) { err = "error: --subdivide must be in 0..4"; return false; } }
+        else if (key == "--binary-ppm") out.binary_ppm = true;
         else if (key == "--output-dir") { if (!need(i, "--output-dir", v)) return false; out.output_dir = v; }
         else if (!a.empty() && a[0] == '-' && a != "-") { err = "error: unexpected argument '" + a + "' found"; return false; }
         else if (!out.has_filename) { out.filename = a; out.has_filename = true; }
@@ -216,7 +218,7 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     rt_scene_destroy(dev);
     std::vector<uint8_t> rgb(n_pixels * 3);
     resolve_pixels(sum.data(), n_pixels, cam.samples_per_pixel, rgb.data());
-    if (!write_ppm_p3(out_filename, rc.image_width, rc.image_height, rgb.data(), err)) return 1;
+    if (!(cli.binary_ppm ? write_ppm_p6 : write_ppm_p3)(out_filename, rc.image_width, rc.image_height, rgb.data(), err)) return 1;
     rs.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     rs.primary_rays = st.primary_rays; rs.scatter_rays = st.scatter_rays; rs.intersection_checks = st.intersection_checks;
     rs.traversal_steps = st.traversal_steps; rs.overlapping_aabb = st.overlapping_aabb; rs.gridbox_intersection_checks = st.gridbox_intersection_checks;

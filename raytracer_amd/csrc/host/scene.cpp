@@ -394,4 +394,17 @@ bool write_ppm_p3(const std::string& path, uint32_t w, uint32_t h, const uint8_t
     return ok;
 }
 
+// Binary PPM (P6): the same 8-bit pixels as the contractual P3 text in a twelfth of the bytes
+bool write_ppm_p6(const std::string& path, uint32_t w, uint32_t h, const uint8_t* rgb, std::string& err) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { err = "Could not open image file: " + path; return false; }
+    const std::string head = "P6\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
+    bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
+    const size_t n = (size_t)w * h * 3;
+    ok = ok && fwrite(rgb, 1, n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) err = "Could not write to image file: " + path;
+    return ok;
+}
+
 } // namespace rth

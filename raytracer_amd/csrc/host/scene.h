@@ -64,5 +64,6 @@ void camera_initialise(const CameraIn& in, rt_camera& out);     // camera.rs:88-
 // camera.rs:75 + color.rs:6-30 → bytes; and the P3 text the reference writes (camera.rs:61,75-76)
 void resolve_pixels(const double* sum, uint64_t n_pixels, uint32_t spp_total, uint8_t* rgb);
 bool write_ppm_p3(const std::string& path, uint32_t w, uint32_t h, const uint8_t* rgb, std::string& err);
+bool write_ppm_p6(const std::string& path, uint32_t w, uint32_t h, const uint8_t* rgb, std::string& err);   // addition: binary
 
 } // namespace rth

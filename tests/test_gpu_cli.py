@@ -58,3 +58,15 @@ def test_draw_boxes_overlay(gpu, tmp_path, extra, name):
     red = (px[:, 0] == 255) & (px[:, 1] == 0) & (px[:, 2] == 0)
     assert red.sum() > 0, "no pure-red edge pixel in the overlay"
     assert "DrawBoxes" in list(csv.DictReader(open(os.path.join(out, "stats.csv"))))[0]["options"]
+
+
+def test_binary_ppm_holds_the_same_pixels(gpu, tmp_path):
+    """--binary-ppm: P6 bytes == the numbers of the contractual P3 text."""
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    base = ["scenes/simple_hollow_glass.json", "--width", "96", "--spp", "3"]
+    assert rt.run(base + ["--output-dir", a]) == 0 and rt.run(base + ["--output-dir", b, "--binary-ppm"]) == 0
+    name = "simple_hollow_glass-bvh.ppm"
+    p3 = np.array(open(os.path.join(a, name)).read().split()[4:], dtype=np.uint8)
+    raw = open(os.path.join(b, name), "rb").read()
+    head = b"P6\n96 54\n255\n"
+    assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], dtype=np.uint8), p3)
