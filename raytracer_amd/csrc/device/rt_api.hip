@@ -202,14 +202,21 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         size_t free_b = 0, total_b = 0;
         HIPCHECK(hipMemGetInfo(&free_b, &total_b));
         uint64_t have = free_b + sc->ws.cap * 196ull;                     // what this scene's workspace already holds counts as free
-        batch_paths = (uint64_t)((double)have * 0.40 / 196.0);
+        batch_paths = (uint64_t)((double)have * 0.75 / 196.0);            // every batch pays a fixed tail of small launches: as few as fit
         if (batch_paths < (1ull << 22)) batch_paths = 1ull << 22;
     }
     uint64_t k64 = batch_paths / WH; if (k64 < 1) k64 = 1; if (s_count && k64 > s_count) k64 = s_count;
     while (k64 > 1 && WH * k64 > 0xf0000000ull) --k64;                      // path ids and the extend fetch counter are 32-bit (headroom for one chunk per wave)
+    if (s_count) { const uint64_t nb = (s_count + k64 - 1) / k64; k64 = (s_count + nb - 1) / nb; }   // equal batches
     uint32_t k = (uint32_t)k64;
     if (WH * k > 0xffffffffull) return fail(RT_E_LIMIT, "batch too large");
     int rc = ensure_workspace(sc, WH * k, max_depth + 2);
+    while (rc == RT_E_HIP && k > 1 && g_batch_paths == 0) {               // the allocation did not fit after all: smaller batches
+        (void)hipGetLastError();
+        sc->ws.release();
+        k = (k + 1) / 2;
+        rc = ensure_workspace(sc, WH * k, max_depth + 2);
+    }
     if (rc) return rc;
     Workspace& w = sc->ws;
 
