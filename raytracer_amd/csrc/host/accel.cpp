@@ -12,7 +12,9 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
+#include <thread>
 
 namespace rth {
 namespace {
@@ -45,14 +47,17 @@ inline int64_t total_key(double d) {                     // f64::total_cmp order
 }
 struct Keyed { int64_t key; uint32_t obj; };
 
+// Scratch of one get_split call chain (one per thread)
+struct SplitScratch { std::vector<Keyed> sorted[3]; std::vector<Box> suffix[3]; };
+
 struct BvhBuilder {
     const Scene& sc; BvhMode mode; Bvh& out;
     std::vector<Box> boxes;
-    std::vector<Keyed> sorted[3];
-    std::vector<Box> suffix;
-    std::vector<double> left_cost;
+    size_t par_min;                                      // nodes with at least this many objects are split with helper threads
 
-    BvhBuilder(const Scene& s, BvhMode m, Bvh& o) : sc(s), mode(m), out(o) {}
+    BvhBuilder(const Scene& s, BvhMode m, Bvh& o) : sc(s), mode(m), out(o), par_min(32768) {
+        if (const char* e = getenv("RT_BVH_PAR_MIN")) { long v = atol(e); if (v > 0) par_min = (size_t)v; }
+    }
 
     Box fold(const uint32_t* objs, size_t n) const {     // objects_to_aabb hittable_list.rs:123-133
         Box b; std::memset(&b, 0, sizeof b);
@@ -73,41 +78,111 @@ struct BvhBuilder {
         for (size_t i = 0; i < n; ++i) { v[i].obj = objs[i]; v[i].key = total_key(sc.centroids[3 * (size_t)objs[i] + axis]); }
         std::stable_sort(v.begin(), v.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
     }
+    // One axis of get_split (bvh.rs:104-134): the stable sort and the best candidate on that axis, as (cost, split);
+    // split 0 = no candidate below `limit`.  Strict `<` keeps the first minimum in split order (bvh.rs:127,152-156).
+    void sweep_axis(const uint32_t* objs, size_t n, int axis, double limit, SplitScratch& sx, double& best, size_t& best_split) const {
+        std::vector<Keyed>& v = sx.sorted[axis];
+        sort_axis(objs, n, axis, v);
+        best = limit; best_split = 0;
+        if (mode == BVH_SAH_PLANE) {                     // :114-123
+            size_t split = n / 2;
+            std::vector<uint32_t> tmp(n); for (size_t i = 0; i < n; ++i) tmp[i] = v[i].obj;
+            Box l = fold(tmp.data(), split), r = fold(tmp.data() + split, n - split);
+            double h = area(l) * (double)split + area(r) * (double)(n - split);
+            if (h < best) { best = h; best_split = split; }
+        } else if (n > 1) {                              // :124-133 as a sweep with suffix boxes
+            std::vector<Box>& suffix = sx.suffix[axis];
+            suffix.resize(n);
+            suffix[n - 1] = boxes[v[n - 1].obj];
+            for (size_t i = n - 1; i-- > 0;) { suffix[i] = boxes[v[i].obj]; grow(suffix[i], suffix[i + 1]); }
+            Box pre = boxes[v[0].obj];
+            for (size_t split = 1; split < n; ++split) {
+                if (split > 1) grow(pre, boxes[v[split - 1].obj]);
+                double h = area(pre) * (double)split + area(suffix[split]) * (double)(n - split);   // :152-154
+                if (h < best) { best = h; best_split = split; }
+            }
+        }
+    }
     // BvhNode::get_split bvh.rs:86-142.  Returns the split position (0 = none); objs is reordered as the
-    // reference reorders the node's slice.
-    size_t get_split(const rt_bvh_node& self, uint32_t* objs, size_t n) {
+    // reference reorders the node's slice.  The three axes are independent given the node's cost: with helpers they run
+    // concurrently and are combined in axis order, each axis having to beat the best of the axes before it (:127).
+    size_t get_split(const rt_bvh_node& self, uint32_t* objs, size_t n, SplitScratch& sx, bool helpers) const {
         if (mode == BVH_NAIVE) {                         // :87-99
             if (n < 3) return 0;
-            sort_axis(objs, n, 0, sorted[0]);
-            for (size_t i = 0; i < n; ++i) objs[i] = sorted[0][i].obj;
+            sort_axis(objs, n, 0, sx.sorted[0]);
+            for (size_t i = 0; i < n; ++i) objs[i] = sx.sorted[0][i].obj;
             return n / 2;
         }
         Box sb; for (int c = 0; c < 3; ++c) { sb.mn[c] = self.min[c]; sb.mx[c] = self.max[c]; }
-        double best = area(sb) * (double)n;              // :101
-        size_t best_split = 0; int best_axis = 0;
-        for (int axis = 0; axis < 3; ++axis) {
-            std::vector<Keyed>& v = sorted[axis];
-            sort_axis(objs, n, axis, v);
-            if (mode == BVH_SAH_PLANE) {                 // :114-123
-                size_t split = n / 2;
-                std::vector<uint32_t> tmp(n); for (size_t i = 0; i < n; ++i) tmp[i] = v[i].obj;
-                Box l = fold(tmp.data(), split), r = fold(tmp.data() + split, n - split);
-                double h = area(l) * (double)split + area(r) * (double)(n - split);
-                if (h < best) { best = h; best_split = split; best_axis = axis; }
-            } else if (n > 1) {                          // :124-133 as a sweep
-                suffix.resize(n);
-                suffix[n - 1] = boxes[v[n - 1].obj];
-                for (size_t i = n - 1; i-- > 0;) { suffix[i] = boxes[v[i].obj]; grow(suffix[i], suffix[i + 1]); }
-                Box pre = boxes[v[0].obj];
-                for (size_t split = 1; split < n; ++split) {
-                    if (split > 1) grow(pre, boxes[v[split - 1].obj]);
-                    double h = area(pre) * (double)split + area(suffix[split]) * (double)(n - split);   // :152-154
-                    if (h < best) { best = h; best_split = split; best_axis = axis; }                 // strict: first minimum wins
-                }
+        const double node_cost = area(sb) * (double)n;   // :101
+        double best = node_cost; size_t best_split = 0; int best_axis = 0;
+        if (helpers) {
+            // each axis finds its own first minimum below the NODE's cost; an axis only wins if it is strictly below the
+            // running best of the earlier axes — the same winner as the sequential scan, because an axis's first minimum
+            // below a smaller limit is the same candidate whenever that candidate is below the limit at all
+            double ab[3]; size_t as[3];
+            std::thread t1([&] { sweep_axis(objs, n, 1, node_cost, sx, ab[1], as[1]); });
+            std::thread t2([&] { sweep_axis(objs, n, 2, node_cost, sx, ab[2], as[2]); });
+            sweep_axis(objs, n, 0, node_cost, sx, ab[0], as[0]);
+            t1.join(); t2.join();
+            for (int axis = 0; axis < 3; ++axis) if (as[axis] != 0 && ab[axis] < best) { best = ab[axis]; best_split = as[axis]; best_axis = axis; }
+        } else {
+            for (int axis = 0; axis < 3; ++axis) {
+                double b; size_t sp;
+                sweep_axis(objs, n, axis, best, sx, b, sp);
+                if (sp != 0) { best = b; best_split = sp; best_axis = axis; }
             }
         }
-        for (size_t i = 0; i < n; ++i) objs[i] = sorted[best_axis][i].obj;                              // :136-140
+        for (size_t i = 0; i < n; ++i) objs[i] = sx.sorted[best_axis][i].obj;                              // :136-140
         return best_split;
+    }
+
+    // BvhNode::sub_divide (bvh.rs:162-180) of one subtree without recursion, into `nodes` with LOCAL numbering
+    // (nodes[0] = the subtree's root).  The reference numbers children at the moment the parent splits
+    // (left = ptr+1, right = ptr+2) and finishes the left subtree first; a LIFO of pending nodes with the right child
+    // pushed below the left reproduces that order.
+    uint32_t build_seq(size_t first, size_t count, std::vector<rt_bvh_node>& nodes, SplitScratch& sx) const {
+        struct Item { uint32_t node, depth; };
+        nodes.clear(); nodes.push_back(leaf(first, count));
+        std::vector<Item> todo; todo.push_back({0u, 1u});
+        uint32_t depth = 1;
+        while (!todo.empty()) {
+            Item it = todo.back(); todo.pop_back();
+            rt_bvh_node self = nodes[it.node];
+            size_t split = get_split(self, out.order.data() + self.first, self.count, sx, false);
+            if (it.depth > depth) depth = it.depth;
+            if (split == 0) continue;
+            uint32_t l = (uint32_t)nodes.size(), r = l + 1;
+            nodes.push_back(leaf(self.first, split));
+            nodes.push_back(leaf(self.first + split, self.count - split));
+            nodes[it.node].is_leaf = 0; nodes[it.node].left = l; nodes[it.node].right = r;
+            todo.push_back({r, it.depth + 1}); todo.push_back({l, it.depth + 1});
+        }
+        return depth;
+    }
+    // The same numbering built from independently built subtrees: with P at local 0 its children sit at 1 and 2, the rest
+    // of the left subtree follows from 3 (the reference finishes it before touching the right child), then the rest of
+    // the right subtree.  Inside a subtree the same rule applies recursively, so remapping indices is all a merge needs.
+    uint32_t build_par(size_t first, size_t count, std::vector<rt_bvh_node>& nodes, unsigned threads) const {
+        SplitScratch sx;
+        if (count < par_min || threads < 2) return build_seq(first, count, nodes, sx);
+        nodes.clear(); nodes.push_back(leaf(first, count));
+        const size_t split = get_split(nodes[0], out.order.data() + first, count, sx, threads >= 3);
+        if (split == 0) return 1;
+        sx = SplitScratch();                             // the big node's scratch is not kept while the subtrees build
+        std::vector<rt_bvh_node> L, R; uint32_t dl = 0, dr = 0;
+        const unsigned tl = threads / 2, tr = threads - tl;
+        std::thread left([&] { dl = build_par(first, split, L, tl); });
+        dr = build_par(first + split, count - split, R, tr);
+        left.join();
+        const uint32_t nl = (uint32_t)L.size(), nr = (uint32_t)R.size();
+        auto map_l = [](uint32_t i) { return i == 0 ? 1u : 3u + (i - 1); };
+        auto map_r = [nl](uint32_t i) { return i == 0 ? 2u : 3u + (nl - 1) + (i - 1); };
+        nodes.resize(1 + (size_t)nl + nr);
+        nodes[0].is_leaf = 0; nodes[0].left = 1; nodes[0].right = 2;
+        for (uint32_t i = 0; i < nl; ++i) { rt_bvh_node n = L[i]; if (!n.is_leaf) { n.left = map_l(n.left); n.right = map_l(n.right); } nodes[map_l(i)] = n; }
+        for (uint32_t i = 0; i < nr; ++i) { rt_bvh_node n = R[i]; if (!n.is_leaf) { n.left = map_r(n.left); n.right = map_r(n.right); } nodes[map_r(i)] = n; }
+        return 1 + (dl > dr ? dl : dr);
     }
 
     bool run(std::string& err) {
@@ -118,26 +193,8 @@ struct BvhBuilder {
         for (size_t i = 0; i < n; ++i) boxes[i] = prim_box(sc.prims[i]);
         out.order.resize(n);
         for (size_t i = 0; i < n; ++i) out.order[i] = (uint32_t)i;
-        out.nodes.clear(); out.nodes.reserve(2 * n);
-        out.nodes.push_back(leaf(0, n));                 // Bvh::new bvh.rs:22
-        // BvhNode::sub_divide (bvh.rs:162-180) without recursion.  The reference numbers children at the moment
-        // the parent splits (left = ptr+1, right = ptr+2) and finishes the left subtree first; a LIFO of pending
-        // nodes with the right child pushed below the left reproduces that order.
-        struct Item { uint32_t node, depth; };
-        std::vector<Item> todo; todo.push_back({0u, 1u});
-        out.depth = 1;
-        while (!todo.empty()) {
-            Item it = todo.back(); todo.pop_back();
-            rt_bvh_node self = out.nodes[it.node];
-            size_t split = get_split(self, out.order.data() + self.first, self.count);
-            if (it.depth > out.depth) out.depth = it.depth;
-            if (split == 0) continue;
-            uint32_t l = (uint32_t)out.nodes.size(), r = l + 1;
-            out.nodes.push_back(leaf(self.first, split));
-            out.nodes.push_back(leaf(self.first + split, self.count - split));
-            out.nodes[it.node].is_leaf = 0; out.nodes[it.node].left = l; out.nodes[it.node].right = r;
-            todo.push_back({r, it.depth + 1}); todo.push_back({l, it.depth + 1});
-        }
+        unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 16) hw = 16;
+        out.depth = build_par(0, n, out.nodes, hw);      // Bvh::new bvh.rs:22
         return true;
     }
 };

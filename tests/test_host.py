@@ -190,3 +190,16 @@ def test_cli_binary_help_and_errors():
     assert r.returncode != 0 and "Can't have the following options at the same time" in r.stderr
     r = subprocess.run([exe, "scenes/simple_fuzzy_metal.json", "--stats"], capture_output=True, text=True)
     assert r.returncode == 0 and "scenes/simple_fuzzy_metal.json & 4 & 2 & 2 & 0" in r.stdout          # main.rs:107-116
+
+
+@pytest.mark.parametrize("mode", ["sah-position", "sah-plane", "naive"])
+def test_parallel_bvh_build_is_identical_to_the_sequential_one(mode, monkeypatch):
+    """Big nodes are split with helper threads and their subtrees built concurrently, then merged by index remapping
+    (accel.cpp: build_par); RT_BVH_PAR_MIN lowers the node size at which that happens so that a small mesh exercises it."""
+    def build(par_min):
+        monkeypatch.setenv("RT_BVH_PAR_MIN", str(par_min))
+        w = load_world("dragon_res4"); w.algorithm, w.bvh_mode = "bvh", mode; w.init()
+        return w.bvh.nodes().tobytes(), w.bvh.order(len(w)).tobytes(), w.bvh.depth
+    seq = build(10 ** 9)
+    for par_min in (64, 1000):
+        assert build(par_min) == seq
