@@ -381,14 +381,23 @@ void resolve_pixels(const double* sum, uint64_t n_pixels, uint32_t spp_total, ui
 bool write_ppm_p3(const std::string& path, uint32_t w, uint32_t h, const uint8_t* rgb, std::string& err) {
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "Could not open image file: " + path; return false; }
-    std::string buf; buf.reserve((size_t)w * h * 12 + 32);
-    buf += "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";   // camera.rs:61
-    char tmp[48];
-    for (uint64_t p = 0; p < (uint64_t)w * h; ++p) {
-        int n = snprintf(tmp, sizeof tmp, "%u %u %u\n", rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2]);   // color.rs:21
-        buf.append(tmp, (size_t)n);
+    // "r g b\n" per pixel (color.rs:21); the 256 possible numbers are formatted once (a 4K frame is 25 M of them)
+    char num[256][4]; uint8_t len[256];
+    for (int v = 0; v < 256; ++v) len[v] = (uint8_t)snprintf(num[v], 4, "%d", v);
+    const std::string head = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";   // camera.rs:61
+    const uint64_t n = (uint64_t)w * h;
+    std::vector<char> buf(head.size() + n * 12);
+    char* p = buf.data();
+    memcpy(p, head.data(), head.size()); p += head.size();
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t v = rgb[3 * i + c];
+            memcpy(p, num[v], len[v]); p += len[v];
+            *p++ = c == 2 ? '\n' : ' ';
+        }
     }
-    bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    const size_t bytes = (size_t)(p - buf.data());
+    bool ok = fwrite(buf.data(), 1, bytes, f) == bytes;
     ok = (fclose(f) == 0) && ok;
     if (!ok) err = "Could not write to image file: " + path;
     return ok;
