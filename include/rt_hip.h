@@ -99,6 +99,13 @@ int rt_scene_set_grid(rt_scene*, const rt_grid_desc*, const double* cell_aabb, c
 enum { RT_OPT_DRAW_BOXES = 1 };
 int rt_scene_set_options(rt_scene*, uint32_t flags);
 
+/* Replaces Bvh::new (src/acceleration/bvh.rs:19-180) for the default BvhSahPosition mode, on the GPU: the same nodes
+ * (indices 0..=node_pointer, bvh.rs:14-15), numbering and object permutation (bvh.rs:13) as the reference's top-down SAH
+ * build.  prims/centroids are host arrays (centroid = Hittable::centroid(), n*3 doubles); nodes_out must hold 2*n_prims
+ * nodes, order_out n_prims indices.  The other build modes (-o bvh-naive, -o bvh-sah-plane) stay on the host. */
+int rt_bvh_build(const rt_prim* prims, const double* centroids, uint32_t n_prims,
+                 rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out);
+
 /* Bytes the BVH extend kernel reads per sibling pair (two box tests) and per primitive test with the layout chosen for
  * this scene by rt_scene_set_bvh: 112 / 80 in general, 112 / 48 for all-sphere scenes, 64 / 48 when every coordinate lies on
  * an f32 lattice (PLY meshes: parser.rs:67-73).  No reference counterpart; bench.py prices the kernel's traffic with it. */

@@ -59,7 +59,7 @@ class RtStats(C.Structure):
 
 
 # every symbol include/rt_hip.h declares (tests check the library exports exactly these)
-RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_trace",
+RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_trace",
                   "rt_generate", "rt_render", "rt_render_device", "rt_scene_destroy", "rt_last_error"]
 
 _hip = None
@@ -88,6 +88,7 @@ def hip_lib():
     lib.rt_scene_set_bvh.argtypes = [C.c_void_p, P(RtBvhNode), C.c_uint32, P(C.c_uint32), C.c_uint32]; lib.rt_scene_set_bvh.restype = C.c_int
     lib.rt_scene_set_grid.argtypes = [C.c_void_p, P(RtGridDesc), P(C.c_double), P(C.c_uint64), P(C.c_uint32)]; lib.rt_scene_set_grid.restype = C.c_int
     lib.rt_scene_set_options.argtypes = [C.c_void_p, C.c_uint32]; lib.rt_scene_set_options.restype = C.c_int
+    lib.rt_bvh_build.argtypes = [P(RtPrim), C.c_void_p, C.c_uint32, P(RtBvhNode), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]; lib.rt_bvh_build.restype = C.c_int
     lib.rt_scene_bvh_layout.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32)]; lib.rt_scene_bvh_layout.restype = C.c_int
     lib.rt_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(RtStats)]
@@ -125,6 +126,7 @@ def host_lib():
     lib.rth_scene_centroids.argtypes = [C.c_void_p]; lib.rth_scene_centroids.restype = P(C.c_double)
     lib.rth_scene_mats.argtypes = [C.c_void_p]; lib.rth_scene_mats.restype = P(RtMaterial)
     lib.rth_bvh_build.argtypes = [C.c_void_p, C.c_int]; lib.rth_bvh_build.restype = C.c_void_p
+    lib.rth_bvh_build_gpu.argtypes = [C.c_void_p]; lib.rth_bvh_build_gpu.restype = C.c_void_p
     lib.rth_bvh_free.argtypes = [C.c_void_p]; lib.rth_bvh_free.restype = None
     lib.rth_bvh_n_nodes.argtypes = [C.c_void_p]; lib.rth_bvh_n_nodes.restype = C.c_uint32
     lib.rth_bvh_depth.argtypes = [C.c_void_p]; lib.rth_bvh_depth.restype = C.c_uint32

@@ -11,6 +11,11 @@
 #include <string>
 #include <vector>
 
+namespace rtb {   // rt_build.hip
+int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+          uint32_t* order_out, uint32_t* depth_out, hipStream_t st, std::string& err);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -374,6 +379,17 @@ int rt_scene_set_options(rt_scene* sc, uint32_t flags) {
     if (!sc) return fail(RT_E_ARG, "null argument");
     if (flags & ~(uint32_t)RT_OPT_DRAW_BOXES) return fail(RT_E_ARG, "unknown option bits 0x%x", flags & ~(uint32_t)RT_OPT_DRAW_BOXES);
     sc->draw_boxes = (flags & RT_OPT_DRAW_BOXES) != 0;
+    return RT_OK;
+}
+
+int rt_bvh_build(const rt_prim* prims, const double* centroids, uint32_t n_prims,
+                 rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!prims || !centroids || !nodes_out || !n_nodes_out || !order_out || !depth_out) return fail(RT_E_ARG, "null argument");
+    for (uint32_t i = 0; i < n_prims; ++i) if (prims[i].type > RT_TRIANGLE) return fail(RT_E_ARG, "primitive %u has unknown type %u", i, prims[i].type);
+    std::string err;
+    const int rc = rtb::build(prims, centroids, n_prims, nodes_out, n_nodes_out, order_out, depth_out, g_stream, err);
+    if (rc != RT_OK) return fail(rc, "%s", err.c_str());
     return RT_OK;
 }
 

@@ -25,6 +25,7 @@ static const char* kHelp =
     "      --spp <N>                Samples per pixel [default: 50] (addition; main.rs:75)\n"
     "      --max-depth <N>          Bounce limit [default: 50]   (addition; main.rs:76)\n"
     "      --seed <N>               Seed of the counter RNG [default: 1] (addition)\n"
+    "      --gpu-build              Build the (default, SAH position) BVH on the GPU instead of on the host (addition)\n"
     "      --binary-ppm             Write the image as binary PPM (P6) instead of P3 text (addition)\n"
     "      --device <N>             GPU index [default: 0] (addition)\n"
     "      --subdivide <L>          Split every PLY triangle into 4, L times (addition; synthetic meshes)\n"
@@ -61,6 +62,7 @@ bool parse_cli(int argc, const char* const* argv, Cli& out, std::string& err) {
         else if (key == "--device") { if (!need(i, "--device", v)) return false; out.device = atoi(v.c_str()); }
         else if (key == "--subdivide") { if (!need(i, "--subdivide", v)) return false; out.subdivide = atoi(v.c_str()); if (out.subdivide < 0 || out.subdivide > 4) { err = "error: --subdivide must be in 0..4"; return false; } }
         else if (key == "--binary-ppm") out.binary_ppm = true;
+        else if (key == "--gpu-build") out.gpu_build = true;
         else if (key == "--output-dir") { if (!need(i, "--output-dir", v)) return false; out.output_dir = v; }
         else if (!a.empty() && a[0] == '-' && a != "-") { err = "error: unexpected argument '" + a + "' found"; return false; }
         else if (!out.has_filename) { out.filename = a; out.has_filename = true; }
@@ -198,7 +200,13 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     if (cli.algorithm == RT_ALGO_BVH) {
         auto t = std::chrono::steady_clock::now();
         Bvh bvh;
-        if (!build_bvh(scene, bvh_mode_of(cli.options), bvh, err)) { rt_scene_destroy(dev); return 1; }
+        if (cli.gpu_build && bvh_mode_of(cli.options) == BVH_SAH_POSITION) {
+            const uint32_t n = (uint32_t)scene.prims.size();
+            bvh.nodes.resize(2 * (size_t)n + 1); bvh.order.resize(n);
+            uint32_t n_nodes = 0;
+            if (rt_bvh_build(scene.prims.data(), scene.centroids.data(), n, bvh.nodes.data(), &n_nodes, bvh.order.data(), &bvh.depth) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
+            bvh.nodes.resize(n_nodes);
+        } else if (!build_bvh(scene, bvh_mode_of(cli.options), bvh, err)) { rt_scene_destroy(dev); return 1; }
         if (rt_scene_set_bvh(dev, bvh.nodes.data(), (uint32_t)bvh.nodes.size(), bvh.order.data(), (uint32_t)bvh.order.size()) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
         fprintf(stderr, "BVH constructed in %.2fs (%zu nodes, depth %u)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(), bvh.nodes.size(), bvh.depth);
     } else if (cli.algorithm == RT_ALGO_GRID) {

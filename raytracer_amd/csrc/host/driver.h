@@ -25,6 +25,7 @@ struct Cli {                                                                // r
     int device = 0;
     int subdivide = 0;                  // synthetic refinement levels for PLY meshes (not a reference feature)
     std::string output_dir = "output";
+    bool gpu_build = false;             // --gpu-build: Bvh::new on the GPU (default SAH mode only)
     bool binary_ppm = false;            // --binary-ppm: write P6 instead of the reference's P3 text (addition)
 };
 

@@ -108,6 +108,7 @@ class HittableList:
         self.bvh_mode = "sah-position"
         self.grid_size = 25.0
         self.draw_boxes = False          # Options.draw_boxes (rtweekend.rs:92), `-o draw-boxes`
+        self.gpu_build = False           # build the SAH-position BVH on the GPU (rt_bvh_build) instead of on the host
         self.bvh = None
         self.grid = None
         self._dev = None
@@ -157,7 +158,11 @@ class HittableList:
     def init(self):
         lib = F.host_lib()
         if self.algorithm == "bvh":
-            h = lib.rth_bvh_build(self._h, self.BVH_MODES[self.bvh_mode])
+            if self.gpu_build and self.bvh_mode == "sah-position":
+                F.hip_lib()
+                h = lib.rth_bvh_build_gpu(self._h)
+            else:
+                h = lib.rth_bvh_build(self._h, self.BVH_MODES[self.bvh_mode])
             if not h:
                 raise RtError(lib.rth_last_error().decode())
             self.bvh = Bvh(h)

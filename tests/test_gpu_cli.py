@@ -22,6 +22,7 @@ for scene, fmt in (("scenes/weekend-final.json", J), ("scenes/dragon_recon/drago
     MATRIX += [(scene, fmt, ["-o", "bvh-naive"]), (scene, fmt, ["-o", "bvh-sah-plane"]), (scene, fmt, ["-o", "bvh-sah-position"]),
                (scene, fmt, ["--algorithm", "grid", "-g", "25"]), (scene, fmt, ["--algorithm", "grid", "-g", "5"])]
 MATRIX += [("scenes/dragon_recon/dragon_vrip_res4.ply", P, ["--camera", str(c)]) for c in range(4)]
+MATRIX += [("scenes/dragon_recon/dragon_vrip_res4.ply", P, ["--gpu-build"]), ("scenes/weekend-final.json", J, ["--gpu-build"])]
 
 
 @pytest.mark.parametrize("scene,fmt,extra", MATRIX)
