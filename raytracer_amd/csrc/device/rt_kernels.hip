@@ -399,7 +399,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 if (all_regular) { lh = slab_fast_d(dLmn, dLmx, inv, ld, lx); rh = slab_fast_d(dRmn, dRmx, inv, rd, rx); }
                 else { lh = slab_d(dLmn, dLmx, inv, ld, lx); rh = slab_d(dRmn, dRmx, inv, rd, rx); }
                 const bool both = lh && rh;
-                const bool go_right = both ? (ld >= rd) : rh;      // bvh.rs:210-211 (tie -> right is `close`), :226-227
+                const bool go_right = rh && (!lh || ld >= rd); // bvh.rs:210-211 (tie -> right is `close`), :226-227; as lane-mask logic
                 if (both) {
                     if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
                         StackEntry e; const uint32_t s = lo & (RT_STK - 1);
