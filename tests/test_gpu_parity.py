@@ -275,3 +275,32 @@ def test_lattice_scale_one_and_f32_exact_json_like_scene(gpu):
     ro, rd = random_rays(20000, 8, -10.0, 10.0)
     assert_trace_equal(w.hit(ro, rd), osc.trace("bvh", ro, rd), "S=1 lattice")
     w.close()
+
+
+def test_full_size_properties_dragon_4k(gpu, monkeypatch):
+    """configs[3] at full size (764 704-triangle stand-in mesh, 3840x2160; 2 of the 128 spp per GPU): the oracle cannot run
+    this in seconds, so size-independent properties — exact primary count; image of samples [0,2) == [0,1) + [1,2) bit for
+    bit; and the compact f32-lattice layout renders the same bits and counters as the f64 layout (RT_COMPACT=0)."""
+    import raytracer_amd as rt
+    from raytracer_amd import HittableList
+    w = HittableList.from_ply("scenes/dragon_recon/dragon_vrip_res3.ply", subdivide=2)
+    w.algorithm = "bvh"; w.gpu_build = True; w.init(); w.upload()
+    assert len(w) == 764704 and w.bvh_layout() == (64, 48)
+    cam = Camera(w.filename, image_width=3840, samples_per_pixel=2)
+    assert (cam.image_width, cam.image_height) == (3840, 2160)
+    img, st = cam.render(w, seed=1)
+    assert st["primary_rays"] == 3840 * 2160 * 2
+    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 2.0 + 1e-9
+    a, sa = cam.render(w, seed=1, s_begin=0, s_count=1)
+    b, sb = cam.render(w, seed=1, s_begin=1, s_count=1)
+    assert np.array_equal(a + b, img) and sa["scatter_rays"] + sb["scatter_rays"] == st["scatter_rays"]
+    try:
+        monkeypatch.setenv("RT_COMPACT", "0"); rt.init(0); w.upload()
+        assert w.bvh_layout() == (112, 80)
+        plain, sp = cam.render(w, seed=1)
+    finally:
+        monkeypatch.setenv("RT_COMPACT", "1"); rt.init(0)
+    assert np.array_equal(plain, img)
+    for k in ("scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb"):
+        assert sp[k] == st[k], k
+    w.close()
