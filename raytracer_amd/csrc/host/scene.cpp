@@ -160,6 +160,40 @@ size_t ply_size(const std::string& t) {
     return 0;
 }
 bool is_float_type(const std::string& t) { return t == "float" || t == "float32"; }
+// Decimal token -> f32, correctly rounded like strtof / Rust's str::parse::<f32>() (ply-rs).  Fast path (Clinger): up to 15
+// significant digits and a power of ten up to 10^22 are exact in f64, so one f64 multiply or divide is the correctly
+// rounded f64; narrowing it is the correctly rounded f32 unless that f64 sits exactly on an f32 rounding boundary, which
+// (like every other shape: hex, inf, nan, long mantissas) goes to strtof.
+float parse_f32(const char* b) {
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* p = b; bool neg = false;
+    if (*p == '-') { neg = true; ++p; } else if (*p == '+') ++p;
+    uint64_t mant = 0; int digits = 0, exp10 = 0; bool any = false;
+    while (*p >= '0' && *p <= '9') { any = true; if (mant || *p != '0') { mant = mant * 10 + (uint64_t)(*p - '0'); ++digits; } ++p; if (digits > 15) return strtof(b, nullptr); }
+    if (*p == '.') { ++p; while (*p >= '0' && *p <= '9') { any = true; if (mant || *p != '0') { mant = mant * 10 + (uint64_t)(*p - '0'); ++digits; } --exp10; ++p; if (digits > 15) return strtof(b, nullptr); } }
+    if (!any) return strtof(b, nullptr);
+    if (*p == 'e' || *p == 'E') {
+        ++p; bool eneg = false; if (*p == '-') { eneg = true; ++p; } else if (*p == '+') ++p;
+        if (!(*p >= '0' && *p <= '9')) return strtof(b, nullptr);
+        int e = 0; while (*p >= '0' && *p <= '9') { e = e * 10 + (*p - '0'); if (e > 10000) return strtof(b, nullptr); ++p; }
+        exp10 += eneg ? -e : e;
+    }
+    if (!(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == 0)) return strtof(b, nullptr);
+    if (exp10 < -22 || exp10 > 22) return strtof(b, nullptr);
+    double d = (double)mant; d = exp10 < 0 ? d / P10[-exp10] : d * P10[exp10];
+    uint64_t bits; memcpy(&bits, &d, 8);
+    if ((bits & 0x1fffffffull) == 0x10000000ull) return strtof(b, nullptr);      // exactly half an f32 ulp in f64: decide on the decimal
+    float f = (float)d;
+    if (!(f - f == 0.0f) || (f != 0.0f && fabsf(f) < 1.17549435e-38f)) return strtof(b, nullptr);   // overflow / subnormal results
+    return neg ? -f : f;
+}
+inline bool parse_int(const char* b, int64_t& v) {
+    const char* p = b; bool neg = false; if (*p == '-') { neg = true; ++p; } else if (*p == '+') ++p;
+    if (!(*p >= '0' && *p <= '9')) return false;
+    int64_t x = 0; int n = 0; while (*p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; if (++n > 17) return false; }
+    if (!(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == 0)) return false;
+    v = neg ? -x : x; return true;
+}
 double read_bin(const unsigned char* p, const std::string& t, bool big) {
     unsigned char b[8]; size_t n = ply_size(t);
     for (size_t i = 0; i < n; ++i) b[i] = big ? p[n - 1 - i] : p[i];
@@ -217,37 +251,43 @@ bool load_ply(const std::string& path, const rt_material& mat, Scene& out, std::
         b = cur; while (cur < end && !(*cur == ' ' || *cur == '\t' || *cur == '\n' || *cur == '\r')) ++cur;
         e2 = cur; return true;
     };
+    std::vector<int64_t> idx;
     for (const PlyElem& el : elems) {
         const bool is_v = el.name == "vertex", is_f = el.name == "face";
+        // per-property facts, looked up once per element instead of once per value
+        struct Fact { int coord; bool f32, is_idx; }; std::vector<Fact> facts;
+        for (const PlyProp& pr : el.props)
+            facts.push_back({pr.name == "x" ? 0 : (pr.name == "y" ? 1 : (pr.name == "z" ? 2 : -1)), is_float_type(pr.type), pr.name == "vertex_indices"});
         if (is_v) { have_v = true; verts.reserve(el.count * 3); }
         if (is_f) { have_f = true; if (!have_v) { err = "Parse error No vertices in PLY file"; return false; } out.prims.reserve(el.count); out.centroids.reserve(el.count * 3); }
         for (size_t r = 0; r < el.count; ++r) {
             double xyz[3] = {0, 0, 0}; bool got[3] = {false, false, false};
-            std::vector<int64_t> idx; bool got_idx = false;
-            for (const PlyProp& pr : el.props) {
+            idx.clear(); bool got_idx = false;
+            for (size_t pi = 0; pi < el.props.size(); ++pi) {
+                const PlyProp& pr = el.props[pi]; const Fact& fa = facts[pi];
                 size_t n = 1;
                 if (pr.is_list) {
-                    if (fmt == 0) { const char *b, *e2; if (!ascii_tok(b, e2)) { err = "Parse error: truncated PLY"; return false; } n = (size_t)strtoll(std::string(b, e2).c_str(), nullptr, 10); }
+                    if (fmt == 0) { const char *b, *e2; if (!ascii_tok(b, e2)) { err = "Parse error: truncated PLY"; return false; } n = (size_t)strtoll(b, nullptr, 10); }   /* the buffer is NUL-terminated and tokens end at white space */
                     else { size_t sz = ply_size(pr.count_type); if ((size_t)(end - cur) < sz) { err = "Parse error: truncated PLY"; return false; } n = (size_t)read_bin((const unsigned char*)cur, pr.count_type, fmt == 2); cur += sz; }
                 }
                 for (size_t k = 0; k < n; ++k) {
-                    double val; float fval = 0; bool is_f32 = is_float_type(pr.type);
+                    double val; float fval = 0; const bool is_f32 = fa.f32;
                     if (fmt == 0) {
                         const char *b, *e2; if (!ascii_tok(b, e2)) { err = "Parse error: truncated PLY"; return false; }
-                        std::string t(b, e2);
-                        if (is_f32) { fval = strtof(t.c_str(), nullptr); val = fval; } else val = strtod(t.c_str(), nullptr);
+                        int64_t iv;
+                        if (is_f32) { fval = parse_f32(b); val = fval; } else if (parse_int(b, iv)) val = (double)iv; else val = strtod(b, nullptr);
                     } else {
                         size_t sz = ply_size(pr.type); if ((size_t)(end - cur) < sz) { err = "Parse error: truncated PLY"; return false; }
                         val = read_bin((const unsigned char*)cur, pr.type, fmt == 2); cur += sz;
                     }
                     if (is_v && !pr.is_list) {
-                        int c = pr.name == "x" ? 0 : (pr.name == "y" ? 1 : (pr.name == "z" ? 2 : -1));
+                        const int c = fa.coord;
                         if (c >= 0) {
                             if (!is_f32) { err = "Parse error Property is not a double value."; return false; }   // parser.rs:67-73 accepts Property::Float only
                             xyz[c] = (double)(float)val * 100.0; got[c] = true;
                         }
                     }
-                    if (is_f && pr.is_list && pr.name == "vertex_indices") { idx.push_back((int64_t)val); got_idx = true; }
+                    if (is_f && pr.is_list && fa.is_idx) { idx.push_back((int64_t)val); got_idx = true; }
                 }
             }
             if (is_v) {

@@ -203,3 +203,12 @@ def test_parallel_bvh_build_is_identical_to_the_sequential_one(mode, monkeypatch
     seq = build(10 ** 9)
     for par_min in (64, 1000):
         assert build(par_min) == seq
+
+
+def test_ply_float_parser_is_correctly_rounded(tmp_path):
+    """parse_f32 (scene.cpp) must equal strtof bit for bit: random decimals, short and long mantissas, exact f32 midpoints."""
+    import subprocess
+    exe = str(tmp_path / "parse_f32_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Iinclude", "-o", exe, "tests/native/parse_f32_check.cpp"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-500:]
