@@ -106,6 +106,14 @@ int rt_scene_set_options(rt_scene*, uint32_t flags);
 int rt_bvh_build(const rt_prim* prims, const double* centroids, uint32_t n_prims,
                  rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out);
 
+/* Replaces HittableList.grid = Grid::new(...) (hittable_list.rs:43, grid.rs:23-61) entirely on the GPU: bins the scene's
+ * objects into the fixed [-100,100]^3 grid of cell size `grid_size` with the reference's table layout (get_index slots,
+ * last-writer cells, origin-cell clones, ascending object order per cell) and installs it as the scene's grid.
+ * rt_scene_get_grid copies the installed tables back (any pointer may be NULL; sizes come from desc->n_cells and *list_len);
+ * the reference has no counterpart for it (its Grid fields are private) — it exists for the parity tests. */
+int rt_scene_build_grid(rt_scene*, double grid_size);
+int rt_scene_get_grid(const rt_scene*, rt_grid_desc* desc, uint64_t* list_len, double* cell_aabb, uint64_t* cell_offset, uint32_t* prim_list);
+
 /* Bytes the BVH extend kernel reads per sibling pair (two box tests) and per primitive test with the layout chosen for
  * this scene by rt_scene_set_bvh: 112 / 80 in general, 112 / 48 for all-sphere scenes, 64 / 48 when every coordinate lies on
  * an f32 lattice (PLY meshes: parser.rs:67-73).  No reference counterpart; bench.py prices the kernel's traffic with it. */

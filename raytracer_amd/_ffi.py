@@ -59,7 +59,7 @@ class RtStats(C.Structure):
 
 
 # every symbol include/rt_hip.h declares (tests check the library exports exactly these)
-RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_trace",
+RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_scene_build_grid", "rt_scene_get_grid", "rt_trace",
                   "rt_generate", "rt_render", "rt_render_device", "rt_scene_destroy", "rt_last_error"]
 
 _hip = None
@@ -89,6 +89,8 @@ def hip_lib():
     lib.rt_scene_set_grid.argtypes = [C.c_void_p, P(RtGridDesc), P(C.c_double), P(C.c_uint64), P(C.c_uint32)]; lib.rt_scene_set_grid.restype = C.c_int
     lib.rt_scene_set_options.argtypes = [C.c_void_p, C.c_uint32]; lib.rt_scene_set_options.restype = C.c_int
     lib.rt_bvh_build.argtypes = [P(RtPrim), C.c_void_p, C.c_uint32, P(RtBvhNode), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]; lib.rt_bvh_build.restype = C.c_int
+    lib.rt_scene_build_grid.argtypes = [C.c_void_p, C.c_double]; lib.rt_scene_build_grid.restype = C.c_int
+    lib.rt_scene_get_grid.argtypes = [C.c_void_p, P(RtGridDesc), P(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p]; lib.rt_scene_get_grid.restype = C.c_int
     lib.rt_scene_bvh_layout.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32)]; lib.rt_scene_bvh_layout.restype = C.c_int
     lib.rt_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(RtStats)]

@@ -14,6 +14,8 @@
 namespace rtb {   // rt_build.hip
 int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node* nodes_out, uint32_t* n_nodes_out,
           uint32_t* order_out, uint32_t* depth_out, hipStream_t st, std::string& err);
+struct GridResult { rt_grid_desc desc; double* cell_aabb; unsigned long long* cell_offset; uint32_t* prim_list; unsigned long long list_len; };
+int build_grid(const rt_prim* prims, uint32_t n, double s, GridResult& out, hipStream_t st, std::string& err);
 }
 
 namespace {
@@ -97,7 +99,7 @@ struct rt_scene {
     DPair64* d_pairs64 = nullptr; DSphere* d_spheres = nullptr;                               // generic pairs; spheres only for all-sphere scenes
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     // grid
-    bool have_grid = false; DGrid grid{};
+    bool have_grid = false; DGrid grid{}; rt_grid_desc grid_desc{}; uint64_t grid_list_len = 0;
     double* d_cell_aabb = nullptr; uint64_t* d_cell_offset = nullptr; uint32_t* d_prim_list = nullptr;
     Workspace ws;
 };
@@ -513,6 +515,40 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     return RT_OK;
 }
 
+static void install_grid(rt_scene* sc, const rt_grid_desc& gd, uint64_t list_len) {      // device tables are already in sc->d_cell_* / d_prim_list
+    DGrid& g = sc->grid;
+    g.box_size = tov(gd.box_size); g.origin = tov(gd.origin); g.end = tov(gd.end); g.total_size = tov(gd.total_size);
+    g.n_cells = gd.n_cells;
+    double tz = gd.total_size[2];                                   /* grid.rs:152: `self.total_size.z() as u32` */
+    g.max_depth = !(tz > 0.0) ? 0u : (tz >= 4294967295.0 ? 0xffffffffu : (uint32_t)tz);
+    g.cell_aabb = sc->d_cell_aabb; g.cell_offset = sc->d_cell_offset; g.prim_list = sc->d_prim_list;
+    sc->grid_desc = gd; sc->grid_list_len = list_len;
+    sc->have_grid = true;
+}
+
+int rt_scene_build_grid(rt_scene* sc, double grid_size) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!sc) return fail(RT_E_ARG, "null argument");
+    rtb::GridResult r; std::string err;
+    const int rc = rtb::build_grid(sc->h_prims.data(), sc->n_prims, grid_size, r, g_stream, err);
+    if (rc != RT_OK) return fail(rc, "%s", err.c_str());
+    if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
+    sc->d_cell_aabb = r.cell_aabb; sc->d_cell_offset = (uint64_t*)r.cell_offset; sc->d_prim_list = r.prim_list;
+    install_grid(sc, r.desc, r.list_len);
+    return RT_OK;
+}
+
+int rt_scene_get_grid(const rt_scene* sc, rt_grid_desc* desc, uint64_t* list_len, double* cell_aabb, uint64_t* cell_offset, uint32_t* prim_list) {
+    if (!sc || !sc->have_grid) return fail(RT_E_STATE, "the scene has no grid");
+    if (desc) *desc = sc->grid_desc;
+    if (list_len) *list_len = sc->grid_list_len;
+    const uint64_t nc = sc->grid_desc.n_cells;
+    if (cell_aabb) HIPCHECK(hipMemcpy(cell_aabb, sc->d_cell_aabb, nc * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    if (cell_offset) HIPCHECK(hipMemcpy(cell_offset, sc->d_cell_offset, (nc + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (prim_list && sc->grid_list_len) HIPCHECK(hipMemcpy(prim_list, sc->d_prim_list, sc->grid_list_len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_scene_set_grid(rt_scene* sc, const rt_grid_desc* gd, const double* cell_aabb, const uint64_t* cell_offset, const uint32_t* prim_list) {
     if (!sc || !gd || !cell_aabb || !cell_offset) return fail(RT_E_ARG, "null argument");
     const uint64_t nc = gd->n_cells;
@@ -530,13 +566,7 @@ int rt_scene_set_grid(rt_scene* sc, const rt_grid_desc* gd, const double* cell_a
     HIPCHECK(hipMemcpy(sc->d_cell_aabb, cell_aabb, nc * 6 * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(sc->d_cell_offset, cell_offset, (nc + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (len) HIPCHECK(hipMemcpy(sc->d_prim_list, prim_list, len * sizeof(uint32_t), hipMemcpyHostToDevice));
-    DGrid& g = sc->grid;
-    g.box_size = tov(gd->box_size); g.origin = tov(gd->origin); g.end = tov(gd->end); g.total_size = tov(gd->total_size);
-    g.n_cells = nc;
-    double tz = gd->total_size[2];                                  /* grid.rs:152: `self.total_size.z() as u32` */
-    g.max_depth = !(tz > 0.0) ? 0u : (tz >= 4294967295.0 ? 0xffffffffu : (uint32_t)tz);
-    g.cell_aabb = sc->d_cell_aabb; g.cell_offset = sc->d_cell_offset; g.prim_list = sc->d_prim_list;
-    sc->have_grid = true;
+    install_grid(sc, *gd, len);
     return RT_OK;
 }
 

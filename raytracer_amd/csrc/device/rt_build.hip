@@ -349,3 +349,231 @@ int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node
 }
 
 } // namespace rtb
+
+// =================================================================================================
+// Grid::new (src/acceleration/grid.rs:23-61, with the fixed bounds of hittable_list.rs:43) on the GPU: the same table as the
+// host builder in host/accel.cpp (which the tests compare it with byte for byte).
+//   * the reference loops over cell corners x,y,z in (-100..100).step_by(size as usize) and stores each cell at
+//     get_index(corner - origin) (grid.rs:64-73), later cells overwriting earlier ones; slots nobody writes keep the
+//     clone of the origin cell (box and object list, grid.rs:24-27), and corners within distance 1 of the origin are
+//     skipped (grid.rs:41-45).  Here: one thread per loop cell, atomicMax of the loop number per slot;
+//   * an object belongs to a cell iff their boxes overlap inclusively (grid.rs:267-271, aabb.rs:113-117), in ascending
+//     object order (grid.rs:274-278).  Here: one wave per object walks the cells its box reaches and emits
+//     (slot, object) pairs; a radix sort of the pairs gives every slot's list in ascending object order.
+namespace rtb {
+
+__host__ __device__ inline unsigned long long sat_usize64(double x) { if (!(x > 0.0)) return 0; if (x >= 18446744073709551616.0) return ~0ull; return (unsigned long long)x; }
+__host__ __device__ inline int sat_i32d(double x) { if (x != x) return 0; if (x <= -2147483648.0) return (int)0x80000000; if (x >= 2147483647.0) return 0x7fffffff; return (int)x; }
+__host__ __device__ inline unsigned long long grid_get_index(const double p[3], const double bs[3], const double total[3]) {   // grid.rs:64-73
+    unsigned long long x = sat_usize64(p[0] / bs[0]), y = sat_usize64(p[1] / bs[1]), z = sat_usize64(p[2] / bs[2]);
+    double size_x = total[0] / bs[0], size_y = total[1] / bs[1];
+    return sat_usize64((double)x + (double)y * size_x + (double)z * size_x * size_y);
+}
+struct GridGeom { double bs[3], origin[3], total[3]; long long start[3]; unsigned long long step[3]; uint32_t dim[3]; unsigned long long n_cells; };
+__host__ __device__ inline double grid_coord(const GridGeom& g, int c, uint32_t k) { return (double)(g.start[c] + (long long)(k * g.step[c])); }
+
+// owner[slot] = 1 + the largest loop number that maps to the slot (0 = nobody: origin clone)
+__global__ void k_grid_owner(GridGeom g, uint32_t n_loop, uint32_t* __restrict__ owner1, uint32_t* __restrict__ bad) {
+    uint32_t lc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= n_loop) return;
+    const uint32_t iz = lc % g.dim[2], iy = (lc / g.dim[2]) % g.dim[1], ix = lc / (g.dim[2] * g.dim[1]);
+    const double mn[3] = {grid_coord(g, 0, ix), grid_coord(g, 1, iy), grid_coord(g, 2, iz)};
+    const double dc[3] = {mn[0] - g.origin[0], mn[1] - g.origin[1], mn[2] - g.origin[2]};
+    if (dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2] <= 1.0) return;                  // grid.rs:41-45
+    const double fin[3] = {(double)sat_i32d(dc[0]), (double)sat_i32d(dc[1]), (double)sat_i32d(dc[2])};
+    const unsigned long long index = grid_get_index(fin, g.bs, g.total);
+    if (index >= g.n_cells) { *bad = 1; return; }
+    atomicMax(&owner1[index], lc + 1u);
+}
+// slot of each loop cell if it is the final owner (else ~0); box of every slot
+__global__ void k_grid_slots(GridGeom g, unsigned long long n_cells, const uint32_t* __restrict__ owner1, unsigned long long* __restrict__ slot_of, double* __restrict__ cell_aabb) {
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_cells) return;
+    double* a = cell_aabb + idx * 6;
+    const uint32_t o = owner1[idx];
+    if (!o) { for (int c = 0; c < 3; ++c) { a[c] = g.origin[c]; a[3 + c] = g.origin[c] + g.bs[c]; } return; }   // origin clone
+    const uint32_t lc = o - 1, iz = lc % g.dim[2], iy = (lc / g.dim[2]) % g.dim[1], ix = lc / (g.dim[2] * g.dim[1]);
+    slot_of[lc] = idx;
+    const double mn[3] = {grid_coord(g, 0, ix), grid_coord(g, 1, iy), grid_coord(g, 2, iz)};
+    for (int c = 0; c < 3; ++c) { a[c] = mn[c]; a[3 + c] = mn[c] + g.bs[c]; }          // GridBox::new grid.rs:261-264
+}
+// the cells along one axis whose [co, co + size] overlaps [lo, hi] inclusively: a contiguous run [k0, k1)
+__device__ inline void grid_axis_run(const GridGeom& g, int c, double lo, double hi, uint32_t& k0, uint32_t& k1) {
+    k0 = k1 = 0; bool open = false;
+    for (uint32_t k = 0; k < g.dim[c]; ++k) {
+        const double cmin = grid_coord(g, c, k), cmax = cmin + g.bs[c];
+        const bool hit = cmax >= lo && cmin <= hi;
+        if (hit && !open) { k0 = k; open = true; }
+        if (hit) k1 = k + 1;
+    }
+}
+// one wave per object: MODE 0 counts its (slot, object) pairs, MODE 1 writes them (key = slot << 32 | object) from `base[obj]`;
+// in both modes the origin flag (overlap with the origin cell's box) is written
+template <int MODE>
+__global__ __launch_bounds__(64) void k_grid_pairs(GridGeom g, const Box6* __restrict__ boxes, uint32_t n, const unsigned long long* __restrict__ slot_of,
+                                                   unsigned long long* __restrict__ pair_count, const unsigned long long* __restrict__ base,
+                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ in_origin) {
+    const uint32_t obj = blockIdx.x, lane = threadIdx.x;
+    if (obj >= n) return;
+    const Box6 b = boxes[obj];
+    __shared__ uint32_t run[6];
+    if (lane < 3) { uint32_t k0, k1; grid_axis_run(g, (int)lane, b.mn[lane], b.mx[lane], k0, k1); run[2 * lane] = k0; run[2 * lane + 1] = k1; }
+    __syncthreads();
+    const uint32_t cx = run[1] - run[0], cy = run[3] - run[2], cz = run[5] - run[4];
+    const unsigned long long total = (unsigned long long)cx * cy * cz;
+    unsigned long long mine = 0, out_pos = MODE ? base[obj] : 0;
+    for (unsigned long long t0 = 0; t0 < total; t0 += 64) {
+        const unsigned long long t = t0 + lane;
+        bool valid = false; unsigned long long slot = 0;
+        if (t < total) {
+            const uint32_t iz = run[4] + (uint32_t)(t % cz), iy = run[2] + (uint32_t)((t / cz) % cy), ix = run[0] + (uint32_t)(t / ((unsigned long long)cz * cy));
+            slot = slot_of[((unsigned long long)ix * g.dim[1] + iy) * g.dim[2] + iz];
+            valid = slot != ~0ull;
+        }
+        const unsigned long long m = __ballot(valid);
+        if (MODE) {
+            if (valid) keys[out_pos + __popcll(m & ((1ull << lane) - 1ull))] = (slot << 32) | obj;
+            out_pos += __popcll(m);
+        } else mine += valid ? 1 : 0;
+    }
+    if (!MODE) {
+        for (int off = 32; off; off >>= 1) mine += __shfl_down(mine, off, 64);
+        if (lane == 0) {
+            pair_count[obj] = mine;
+            bool o = true;                                           // aabb.rs:113-117 against the origin cell's box
+            for (int c = 0; c < 3; ++c) o = o && (g.origin[c] + g.bs[c] >= b.mn[c]) && (g.origin[c] <= b.mx[c]);
+            in_origin[obj] = o ? 1u : 0u;
+        }
+    }
+}
+__global__ void k_grid_count(const unsigned long long* __restrict__ keys, unsigned long long L, unsigned long long* __restrict__ cell_count) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) atomicAdd(&cell_count[keys[i] >> 32], 1ull);
+}
+__global__ void k_grid_clone_counts(unsigned long long n_cells, const uint32_t* __restrict__ owner1, unsigned long long n_origin, unsigned long long* __restrict__ cell_count) {
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_cells && !owner1[idx]) cell_count[idx] = n_origin;
+}
+// sorted pairs -> lists: pair i of slot s lands at offset[s] + (i - first pair of s); the first pair of s is found by a search
+__global__ void k_grid_fill(const unsigned long long* __restrict__ keys, unsigned long long L, const unsigned long long* __restrict__ cell_offset,
+                            const unsigned long long* __restrict__ pair_start, uint32_t* __restrict__ prim_list) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const unsigned long long s = keys[i] >> 32;
+    prim_list[cell_offset[s] + (i - pair_start[s])] = (uint32_t)keys[i];
+}
+__global__ void k_grid_clone_fill(unsigned long long n_cells, const uint32_t* __restrict__ owner1, const unsigned long long* __restrict__ cell_offset,
+                                  const uint32_t* __restrict__ origin_list, uint32_t n_origin, uint32_t* __restrict__ prim_list) {
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_cells || owner1[idx]) return;
+    for (uint32_t k = 0; k < n_origin; ++k) prim_list[cell_offset[idx] + k] = origin_list[k];
+}
+__global__ void k_grid_boxes(const rt_prim* __restrict__ prims, uint32_t n, Box6* __restrict__ boxes) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_prim p = prims[i]; Box6 b;
+    if (p.type == RT_SPHERE) { for (int c = 0; c < 3; ++c) { b.mn[c] = p.v[c] - p.v[3]; b.mx[c] = p.v[c] + p.v[3]; } }
+    else for (int c = 0; c < 3; ++c) { b.mn[c] = fmin(fmin(p.v[c], p.v[3 + c]), p.v[6 + c]); b.mx[c] = fmax(fmax(p.v[c], p.v[3 + c]), p.v[6 + c]); }
+    boxes[i] = b;
+}
+__global__ void k_grid_origin_list(const uint32_t* __restrict__ in_origin, const uint32_t* __restrict__ rank, uint32_t n, uint32_t* __restrict__ origin_list) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && in_origin[i]) origin_list[rank[i]] = i;
+}
+
+struct GridResult { rt_grid_desc desc; double* cell_aabb; unsigned long long* cell_offset; uint32_t* prim_list; unsigned long long list_len; };
+
+// Device buffers of the result are owned by the caller afterwards (hipFree); everything else is freed here.
+int build_grid(const rt_prim* prims, uint32_t n, double s, GridResult& out, hipStream_t st, std::string& err) {
+    if (!(s >= 1.0)) { err = "grid size must be >= 1 (the reference's step_by panics on 0)"; return RT_E_ARG; }
+    GridGeom g;
+    for (int c = 0; c < 3; ++c) { g.bs[c] = s; g.origin[c] = -100.0; g.total[c] = 200.0; }                         // hittable_list.rs:43
+    g.n_cells = sat_usize64((g.total[0] / s) * (g.total[1] / s) * (g.total[2] / s));                                 // grid.rs:27
+    if (g.n_cells == 0) { err = "grid has no cells"; return RT_E_ARG; }
+    unsigned long long n_loop = 1;
+    for (int c = 0; c < 3; ++c) {                                                                                     // grid.rs:29-38
+        const long long a = sat_i32d(g.origin[c]), b = sat_i32d(100.0); const unsigned long long stp = sat_usize64(g.bs[c]);
+        g.start[c] = a; g.step[c] = stp; g.dim[c] = (uint32_t)((b - a + (long long)stp - 1) / (long long)stp);
+        n_loop *= g.dim[c];
+    }
+    if (n_loop >= 0xffffffffull || g.n_cells >= 0xffffffffull) { err = "grid too fine"; return RT_E_LIMIT; }
+    memset(&out, 0, sizeof out);
+    for (int c = 0; c < 3; ++c) { out.desc.box_size[c] = s; out.desc.origin[c] = -100.0; out.desc.end[c] = 100.0; out.desc.total_size[c] = 200.0; }
+    out.desc.n_cells = g.n_cells;
+
+    DevBuf buf;
+    const uint32_t TB = 256;
+    auto blocks = [&](unsigned long long m) { return dim3((unsigned)((m + TB - 1) / TB)); };
+    rt_prim* d_prims; Box6* boxes; uint32_t *owner1, *bad, *in_origin, *rank, *origin_list; unsigned long long *slot_of, *pair_count, *pair_base;
+    RTB_ALLOC(d_prims, rt_prim, n); RTB_ALLOC(boxes, Box6, n); RTB_ALLOC(owner1, uint32_t, g.n_cells); RTB_ALLOC(bad, uint32_t, 1);
+    RTB_ALLOC(in_origin, uint32_t, (size_t)n + 1); RTB_ALLOC(rank, uint32_t, (size_t)n + 1); RTB_ALLOC(origin_list, uint32_t, n);
+    RTB_ALLOC(slot_of, unsigned long long, n_loop); RTB_ALLOC(pair_count, unsigned long long, (size_t)n + 1); RTB_ALLOC(pair_base, unsigned long long, (size_t)n + 1);
+    unsigned long long *cell_count, *pair_start;
+    RTB_ALLOC(cell_count, unsigned long long, g.n_cells + 1); RTB_ALLOC(pair_start, unsigned long long, g.n_cells + 1);
+    // results (kept on success)
+    double* cell_aabb = nullptr; unsigned long long* cell_offset = nullptr; uint32_t* prim_list = nullptr;
+    auto drop = [&]() { if (cell_aabb) (void)hipFree(cell_aabb); if (cell_offset) (void)hipFree(cell_offset); if (prim_list) (void)hipFree(prim_list); };
+#define RTB_GCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + " failed: " + hipGetErrorString(e_); drop(); return RT_E_HIP; } } while (0)
+    RTB_GCHECK(hipMalloc(&cell_aabb, g.n_cells * 6 * sizeof(double)));
+    RTB_GCHECK(hipMalloc(&cell_offset, (g.n_cells + 1) * sizeof(unsigned long long)));
+
+    if (n) RTB_GCHECK(hipMemcpyAsync(d_prims, prims, (size_t)n * sizeof(rt_prim), hipMemcpyHostToDevice, st));
+    RTB_GCHECK(hipMemsetAsync(owner1, 0, g.n_cells * sizeof(uint32_t), st));
+    RTB_GCHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), st));
+    RTB_GCHECK(hipMemsetAsync(slot_of, 0xff, n_loop * sizeof(unsigned long long), st));
+    RTB_GCHECK(hipMemsetAsync(cell_count, 0, (g.n_cells + 1) * sizeof(unsigned long long), st));
+    RTB_GCHECK(hipMemsetAsync(pair_count, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
+    RTB_GCHECK(hipMemsetAsync(in_origin, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
+    if (n) hipLaunchKernelGGL(k_grid_boxes, blocks(n), dim3(TB), 0, st, d_prims, n, boxes);
+    hipLaunchKernelGGL(k_grid_owner, blocks(n_loop), dim3(TB), 0, st, g, (uint32_t)n_loop, owner1, bad);
+    hipLaunchKernelGGL(k_grid_slots, blocks(g.n_cells), dim3(TB), 0, st, g, g.n_cells, owner1, slot_of, cell_aabb);
+    if (n) hipLaunchKernelGGL(k_grid_pairs<0>, dim3(n), dim3(64), 0, st, g, boxes, n, slot_of, pair_count, pair_base, (unsigned long long*)nullptr, in_origin);
+
+    size_t tmp_bytes = 0, need = 0;
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, pair_count, pair_base, (int)n + 1, st)); tmp_bytes = std::max(tmp_bytes, need);
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in_origin, rank, (int)n + 1, st)); tmp_bytes = std::max(tmp_bytes, need);
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, cell_count, cell_offset, (int)(g.n_cells + 1), st)); tmp_bytes = std::max(tmp_bytes, need);
+    void* tmp; RTB_ALLOC(tmp, unsigned char, tmp_bytes);
+    size_t tb = tmp_bytes;
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, pair_count, pair_base, (int)n + 1, st));
+    tb = tmp_bytes;
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, in_origin, rank, (int)n + 1, st));
+    unsigned long long L = 0; uint32_t n_origin = 0, h_bad = 0;
+    RTB_GCHECK(hipMemcpyAsync(&L, pair_base + n, sizeof L, hipMemcpyDeviceToHost, st));
+    RTB_GCHECK(hipMemcpyAsync(&n_origin, rank + n, sizeof n_origin, hipMemcpyDeviceToHost, st));
+    RTB_GCHECK(hipMemcpyAsync(&h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, st));
+    RTB_GCHECK(hipStreamSynchronize(st));
+    if (h_bad) { err = "grid size does not tile the 200^3 world (the reference panics: index out of bounds)"; drop(); return RT_E_ARG; }
+    if (L >= 0x7fffffffull) { err = "grid object lists too long for the device builder"; drop(); return RT_E_LIMIT; }
+    if (n) hipLaunchKernelGGL(k_grid_origin_list, blocks(n), dim3(TB), 0, st, in_origin, rank, n, origin_list);
+
+    unsigned long long *keys_a = nullptr, *keys_b = nullptr;
+    if (L) {
+        RTB_ALLOC(keys_a, unsigned long long, L); RTB_ALLOC(keys_b, unsigned long long, L);
+        hipLaunchKernelGGL(k_grid_pairs<1>, dim3(n), dim3(64), 0, st, g, boxes, n, slot_of, pair_count, pair_base, keys_a, in_origin);
+        size_t sort_bytes = 0;
+        RTB_GCHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_a, keys_b, (int)L, 0, 64, st));
+        void* sort_tmp; RTB_ALLOC(sort_tmp, unsigned char, sort_bytes);
+        RTB_GCHECK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys_a, keys_b, (int)L, 0, 64, st));
+        hipLaunchKernelGGL(k_grid_count, blocks(L), dim3(TB), 0, st, keys_b, L, cell_count);
+    }
+    // first pair of every slot (before the clones are counted in), then the final CSR offsets with the clones
+    tb = tmp_bytes;
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cell_count, pair_start, (int)(g.n_cells + 1), st));
+    hipLaunchKernelGGL(k_grid_clone_counts, blocks(g.n_cells), dim3(TB), 0, st, g.n_cells, owner1, (unsigned long long)n_origin, cell_count);
+    tb = tmp_bytes;
+    RTB_GCHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cell_count, cell_offset, (int)(g.n_cells + 1), st));
+    unsigned long long len = 0;
+    RTB_GCHECK(hipMemcpyAsync(&len, cell_offset + g.n_cells, sizeof len, hipMemcpyDeviceToHost, st));
+    RTB_GCHECK(hipStreamSynchronize(st));
+    RTB_GCHECK(hipMalloc(&prim_list, (len ? len : 1) * sizeof(uint32_t)));
+    if (L) hipLaunchKernelGGL(k_grid_fill, blocks(L), dim3(TB), 0, st, keys_b, L, cell_offset, pair_start, prim_list);
+    if (n_origin) hipLaunchKernelGGL(k_grid_clone_fill, blocks(g.n_cells), dim3(TB), 0, st, g.n_cells, owner1, cell_offset, origin_list, n_origin, prim_list);
+    RTB_GCHECK(hipStreamSynchronize(st));
+    RTB_GCHECK(hipGetLastError());
+#undef RTB_GCHECK
+    out.cell_aabb = cell_aabb; out.cell_offset = cell_offset; out.prim_list = prim_list; out.list_len = len;
+    return RT_OK;
+}
+
+} // namespace rtb

@@ -211,9 +211,14 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
         fprintf(stderr, "BVH constructed in %.2fs (%zu nodes, depth %u)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(), bvh.nodes.size(), bvh.depth);
     } else if (cli.algorithm == RT_ALGO_GRID) {
         auto t = std::chrono::steady_clock::now();
-        Grid grid;
-        if (!build_grid(scene, cli.grid_size, grid, err)) { rt_scene_destroy(dev); return 1; }
-        if (rt_scene_set_grid(dev, &grid.desc, grid.cell_aabb.data(), grid.cell_offset.data(), grid.prim_list.data()) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
+        if (cli.gpu_build) {
+            if (!(cli.grid_size >= 1.0)) { err = "grid size must be at least 1"; rt_scene_destroy(dev); return 1; }
+            if (rt_scene_build_grid(dev, cli.grid_size) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
+        } else {
+            Grid grid;
+            if (!build_grid(scene, cli.grid_size, grid, err)) { rt_scene_destroy(dev); return 1; }
+            if (rt_scene_set_grid(dev, &grid.desc, grid.cell_aabb.data(), grid.cell_offset.data(), grid.prim_list.data()) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
+        }
         fprintf(stderr, "Grid constructed in %.2fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count());
     }
     rs.init_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();

@@ -25,7 +25,7 @@ struct Cli {                                                                // r
     int device = 0;
     int subdivide = 0;                  // synthetic refinement levels for PLY meshes (not a reference feature)
     std::string output_dir = "output";
-    bool gpu_build = false;             // --gpu-build: Bvh::new on the GPU (default SAH mode only)
+    bool gpu_build = false;             // --gpu-build: Bvh::new (default SAH mode) / Grid::new on the GPU
     bool binary_ppm = false;            // --binary-ppm: write P6 instead of the reference's P3 text (addition)
 };
 

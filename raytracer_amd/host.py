@@ -108,10 +108,11 @@ class HittableList:
         self.bvh_mode = "sah-position"
         self.grid_size = 25.0
         self.draw_boxes = False          # Options.draw_boxes (rtweekend.rs:92), `-o draw-boxes`
-        self.gpu_build = False           # build the SAH-position BVH on the GPU (rt_bvh_build) instead of on the host
+        self.gpu_build = False           # build the SAH-position BVH / the grid on the GPU (rt_bvh_build, rt_scene_build_grid)
         self.bvh = None
         self.grid = None
         self._dev = None
+        self._grid_on_device = False
 
     # ---- construction
     @classmethod
@@ -166,7 +167,10 @@ class HittableList:
             if not h:
                 raise RtError(lib.rth_last_error().decode())
             self.bvh = Bvh(h)
+        elif self.algorithm == "grid" and self.gpu_build:
+            self.grid = None; self._grid_on_device = True          # binned by upload(), on the GPU
         elif self.algorithm == "grid":
+            self._grid_on_device = False
             h = lib.rth_grid_build(self._h, float(self.grid_size))
             if not h:
                 raise RtError(lib.rth_last_error().decode())
@@ -189,6 +193,8 @@ class HittableList:
         if self.grid is not None:
             _hip_check(hip.rt_scene_set_grid(self._dev, host.rth_grid_desc(self.grid._h), host.rth_grid_cell_aabb(self.grid._h),
                                              host.rth_grid_cell_offset(self.grid._h), host.rth_grid_prim_list(self.grid._h)))
+        elif self._grid_on_device:
+            _hip_check(hip.rt_scene_build_grid(self._dev, float(self.grid_size)))
         return self
 
     # ---- Hittable::hit for a batch of rays (hittable_list.rs:65-102), on the GPU
@@ -204,6 +210,21 @@ class HittableList:
         _hip_check(F.hip_lib().rt_trace(self._dev, algo, orig.ctypes.data, direction.ctypes.data, n, tmin, tmax,
                                         prim.ctypes.data, t.ctypes.data, tp.ctypes.data, hit.ctypes.data, C.byref(st)))
         return {"prim": prim, "t": t, "tp": tp, "hit": (hit & 1).astype(bool), "edge": (hit & 2).astype(bool), "stats": st.as_dict()}
+
+    def build_grid_on_device(self, grid_size=None):
+        """Grid::new on the GPU (rt_scene_build_grid): bins the uploaded objects and installs the grid; no host tables."""
+        if self._dev is None:
+            self.upload()
+        _hip_check(F.hip_lib().rt_scene_build_grid(self._dev, float(self.grid_size if grid_size is None else grid_size)))
+        return self
+
+    def device_grid(self):
+        """(desc, cell_aabb, cell_offset, prim_list) of the grid installed on the device, copied back."""
+        hip = F.hip_lib(); d = F.RtGridDesc(); ln = C.c_uint64()
+        _hip_check(hip.rt_scene_get_grid(self._dev, C.byref(d), C.byref(ln), None, None, None))
+        aabb = np.empty((d.n_cells, 6)); off = np.empty(d.n_cells + 1, np.uint64); pl = np.empty(max(ln.value, 1), np.uint32)
+        _hip_check(hip.rt_scene_get_grid(self._dev, None, None, aabb.ctypes.data, off.ctypes.data, pl.ctypes.data))
+        return d, aabb, off, pl[:ln.value]
 
     def bvh_layout(self):
         """(bytes per sibling pair, bytes per primitive) the BVH extend kernel reads for this scene."""

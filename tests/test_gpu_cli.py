@@ -71,3 +71,15 @@ def test_binary_ppm_holds_the_same_pixels(gpu, tmp_path):
     raw = open(os.path.join(b, name), "rb").read()
     head = b"P6\n96 54\n255\n"
     assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], dtype=np.uint8), p3)
+
+
+def test_gpu_built_grid_gives_the_same_image(gpu, tmp_path):
+    """--gpu-build with --algorithm grid (rt_scene_build_grid): same tables, hence the same pixels and counters."""
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    base = ["scenes/weekend-final.json", "--width", "96", "--spp", "2", "--algorithm", "grid", "-g", "5"]
+    assert rt.run(base + ["--output-dir", a]) == 0 and rt.run(base + ["--output-dir", b, "--gpu-build"]) == 0
+    name = "weekend-final-grid-size=5.ppm"
+    assert open(os.path.join(a, name)).read() == open(os.path.join(b, name)).read()
+    ra, rb = (list(csv.DictReader(open(os.path.join(d, "stats.csv"))))[0] for d in (a, b))
+    for k in ("intersection_checks", "traversal_steps", "gridbox_intersection_checks", "scatter_rays"):
+        assert ra[k] == rb[k], k
