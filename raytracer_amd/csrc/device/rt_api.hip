@@ -39,6 +39,7 @@ uint64_t g_batch_paths = 0;           // paths in flight per batch; 0 = size fro
 uint32_t g_tune = (8u << 16) | (1u << 8) | 1u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
 unsigned long long* g_dbg = nullptr;  // diagnostic builds (-DRT_STAMPS) only
 int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
+bool g_bounce_log = false;            // RT_BOUNCE_LOG=1: per-bounce kernel times on stderr while profiling is on
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 
 struct EventPool {
@@ -269,6 +270,11 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             end_span();
             HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
+            if (g_profiling && g_bounce_log) {                           // diagnostic: RT_BOUNCE_LOG=1 with profiling on
+                float fe = 0, fs = 0; const size_t ns = spans.size();
+                (void)hipEventElapsedTime(&fe, spans[ns - 2].a, spans[ns - 2].b); (void)hipEventElapsedTime(&fs, spans[ns - 1].a, spans[ns - 1].b);
+                fprintf(stderr, "bounce %2u: extend %9.3f ms, shade %8.3f ms, rays out %u\n", b, fe, fs, *w.h_count);
+            }
             if (g_profiling) drain_spans();
             if (*w.h_count == 0) break;
         }
@@ -312,6 +318,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
+    if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
 #ifdef RT_STAMPS
