@@ -83,6 +83,77 @@ RT_DEV V3 random_unit(Rng& g) {                                                 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative form of the two rejection samplers.  A wave that runs `random_unit` lane by lane loops as long as its
+// unluckiest lane (6.4 tries expected for 64 lanes, 1.9 for one); here the lanes that are done compute further tries
+// of the lanes that are not.  The tries of a path are fixed by its counter (try t of random_unit = draws 3t..3t+2, try t
+// of random_in_unit_disk = draws first+2t, first+2t+1), so any lane can evaluate any path's try, and the owner takes its
+// first accepted try in order: the result is bit for bit what the sequential loop returns.
+RT_DEV double draw_of(uint32_t lo32, uint32_t hi32) { return (double)((((uint64_t)hi32 << 32) | lo32) >> 11) * (1.0 / 9007199254740992.0); }
+RT_DEV void rng_block(uint32_t k0, uint32_t k1, uint32_t lo, uint32_t hi, uint32_t stream, uint32_t n, double& a, double& b) {
+    uint32_t c[4] = {lo, hi, stream, n};
+    philox4x32_10(c, k0, k1);
+    a = draw_of(c[0], c[1]); b = draw_of(c[2], c[3]);
+}
+struct CoopLds { uint2 owner[64]; double px[64], py[64], pz[64]; };       // one per wave
+RT_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// One work item of a path's sampler.  DIM 3: tries 2j and 2j+1 of random_unit (blocks 3j..3j+2 of the stream, first draw 0),
+// returns the first accepted candidate p (not yet normalised).  DIM 2: try j of random_in_unit_disk (block base + j).
+template <int DIM>
+RT_DEV bool reject_item(uint32_t k0, uint32_t k1, uint32_t lo, uint32_t hi, uint32_t stream, uint32_t base, uint32_t j, V3& p) {
+    if (DIM == 2) {
+        double a, b; rng_block(k0, k1, lo, hi, stream, base + j, a, b);
+        p = v3(-1.0 + 2.0 * a, -1.0 + 2.0 * b, 0.0);
+        return length_squared(p) < 1.0;                                    // vec3.rs:27
+    } else {
+        double d0, d1, d2, d3, d4, d5;
+        rng_block(k0, k1, lo, hi, stream, base + 3u * j, d0, d1);
+        rng_block(k0, k1, lo, hi, stream, base + 3u * j + 1u, d2, d3);
+        rng_block(k0, k1, lo, hi, stream, base + 3u * j + 2u, d4, d5);
+        const V3 pa = v3(-1.0 + 2.0 * d0, -1.0 + 2.0 * d1, -1.0 + 2.0 * d2), pb = v3(-1.0 + 2.0 * d3, -1.0 + 2.0 * d4, -1.0 + 2.0 * d5);
+        const double la = length_squared(pa), lb = length_squared(pb);
+        const bool aa = 1e-160 < la && la <= 1.0, ab = 1e-160 < lb && lb <= 1.0;   // vec3.rs:37
+        p = aa ? pa : pb;
+        return aa || ab;
+    }
+}
+// Every lane of the wave must call this (converged); `need` says whether the lane wants a sample.  Returns the accepted
+// candidate of the lane's own path.
+template <int DIM>
+RT_DEV V3 coop_reject(bool need, uint32_t k0, uint32_t k1, uint32_t lo, uint32_t hi, uint32_t stream, uint32_t base, CoopLds* L) {
+    V3 res = v3(0, 0, 0);
+    if (__builtin_amdgcn_ballot_w64(need) == 0) return res;
+    const uint32_t lane = threadIdx.x & 63;
+    bool undone = need;
+    { V3 p; const bool acc = reject_item<DIM>(k0, k1, lo, hi, stream, base, 0, p); if (undone && acc) { res = p; undone = false; } }
+    uint32_t next = 1;
+    for (;;) {
+        const unsigned long long U = __builtin_amdgcn_ballot_w64(undone);
+        if (U == 0) break;
+        const uint32_t n_u = (uint32_t)__builtin_popcountll(U);
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(64u / n_u);     // 2^lg helpers per unfinished path
+        const uint32_t rank = (uint32_t)__builtin_popcountll(U & ((1ull << lane) - 1ull));
+        if (undone) L->owner[rank] = make_uint2(lo, hi);
+        wave_sync();
+        const uint32_t orank = lane >> lg, off = lane & ((1u << lg) - 1u);
+        const bool helper = orank < n_u;
+        const uint2 ow = L->owner[helper ? orank : 0u];
+        V3 p; const bool acc = reject_item<DIM>(k0, k1, ow.x, ow.y, stream, base, next + off, p) && helper;
+        L->px[lane] = p.x; L->py[lane] = p.y; L->pz[lane] = p.z;
+        const unsigned long long A = __builtin_amdgcn_ballot_w64(acc);
+        wave_sync();
+        if (undone) {
+            const unsigned long long mine = (A >> (rank << lg)) & (lg == 6u ? ~0ull : ((1ull << (1u << lg)) - 1ull));
+            if (mine) { const uint32_t h = (rank << lg) + (uint32_t)__builtin_ctzll(mine); res = v3(L->px[h], L->py[h], L->pz[h]); undone = false; }
+        }
+        wave_sync();
+        next += 1u << lg;
+    }
+    return res;
+}
 // ---------------------------------------------------------------------------------------------
 // Device scene records.
 struct __align__(16) DPrim {       // 80 B: one Hittable (sphere.rs:13-17 / triangle.rs:12-18)

@@ -3,7 +3,9 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 128          // extend kernels: two wave64 per workgroup
-#define RT_SBLOCK 256         // streaming kernels (generate, shade, accumulate): block-level queue compaction
+#ifndef RT_SBLOCK
+#define RT_SBLOCK 256
+#endif                        // streaming kernels (generate, shade, accumulate): block-level queue compaction
 
 // SoA ray queue in HBM: one entry per live path (origin, direction, throughput, path id)
 struct RayQ { double *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb; uint32_t* id; };

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_generate(DCamera cam, DRootBox ro
                                                         RayQ out, uint32_t* count_out, double* __restrict__ rad, uint64_t rad_stride,
                                                         unsigned long long* stats) {
     __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
+    __shared__ CoopLds s_coop[RT_SBLOCK / 64];
     const uint32_t W = cam.W, H = cam.H;
     const uint32_t tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y, n_waves = n_tiles * s_count;
@@ -82,16 +83,17 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_generate(DCamera cam, DRootBox ro
         V3 orig = v3(0, 0, 0), dir = v3(0, 0, 0);
         const uint32_t pix = j * W + i;
         const uint32_t id = s_local * (W * H) + pix;
+        // draws 0, 1 = sample_square; from draw 2 on: the tries of random_in_unit_disk, shared out over the wave
+        const bool lens = cam.defocus_angle > 0.0;
+        double ox = 0.0, oy = 0.0;
+        if (valid) { rng_block((uint32_t)seed, (uint32_t)(seed >> 32), pix, s_base + s_local, 0u, 0u, ox, oy); ox = ox - 0.5; oy = oy - 0.5; }
+        const V3 disk = coop_reject<2>(valid && lens, (uint32_t)seed, (uint32_t)(seed >> 32), pix, s_base + s_local, 0u, 1u, &s_coop[wave]);
         if (valid) {
-            Rng g(seed, pix, s_base + s_local, 0);
-            double ox = g.next() - 0.5;
-            double oy = g.next() - 0.5;
             V3 pixel_sample = cam.pixel00 + (((double)i + ox) * cam.du) + (((double)j + oy) * cam.dv);
-            if (cam.defocus_angle <= 0.0) {
+            if (!lens) {
                 orig = cam.center;
             } else {
-                V3 p = random_in_unit_disk(g);
-                orig = cam.center + (p.x * cam.ddu) + (p.y * cam.ddv);
+                orig = cam.center + (disk.x * cam.ddu) + (disk.y * cam.ddv);
             }
             dir = pixel_sample - orig;
             if (root.enabled) {
@@ -652,6 +654,7 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
                                                     uint32_t bounce, uint32_t max_depth, uint64_t seed,
                                                     unsigned long long* stats) {
     __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
+    __shared__ CoopLds s_coop[RT_SBLOCK / 64];
     const uint64_t n = (uint64_t)*count_in;
     const uint64_t T = (uint64_t)gridDim.x * RT_SBLOCK;
     uint64_t c_scatter = 0;
@@ -661,13 +664,16 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
         bool alive = false;
         V3 no = v3(0, 0, 0), nd = v3(0, 0, 0), thr = v3(0, 0, 0);
         uint32_t id = 0;
+        // part 1: the hit record (or the path's end); which lanes will call Vec3::random_unit()
+        V3 d = v3(0, 0, 0), p = v3(0, 0, 0), normal = v3(0, 0, 0), radiance = v3(0, 0, 0);
+        bool surface = false, front_face = false;
+        DMat m; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0.0; m.param = 0.0; m.type = 2u; m.pad = 0u;
         if (valid) {
             V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
-            V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
+            d = v3(in.dx[q], in.dy[q], in.dz[q]);
             thr = v3(in.tr[q], in.tg[q], in.tb[q]);
             id = in.id[q];
             int32_t pi = hit_prim_[q];
-            V3 radiance = v3(0, 0, 0);
             if (pi == RT_HIT_EDGE) {                                  // camera.rs:162-164,178-180: Color::red()
                 radiance = thr * v3(1.0, 0.0, 0.0);
             } else if (pi < 0) {                                      // camera.rs:182-184
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
             } else {
                 DPrim P = prims[pi];
                 double tp = hit_tp[q];
-                V3 p = o + (tp * d);
+                p = o + (tp * d);
                 V3 outward;
                 if (P.tm >> 31) {
                     V3 v0 = v3(P.v[0], P.v[1], P.v[2]), v1 = v3(P.v[3], P.v[4], P.v[5]), v2 = v3(P.v[6], P.v[7], P.v[8]);
@@ -684,15 +690,21 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
                     V3 pn = hit_tn ? o + (hit_tn[q] * d) : p;            // rec.p as it was when the sphere was accepted
                     outward = (pn - v3(P.v[0], P.v[1], P.v[2])) / P.v[3];
                 }
-                bool front_face = dot(d, outward) < 0.0;              // hittable.rs:26-29
-                V3 normal = front_face ? outward : -outward;
-                DMat m = mats[P.tm & 0x7fffffffu];
-                Rng g(seed, id % WH, s_base + id / WH, 1u + bounce);
+                front_face = dot(d, outward) < 0.0;                   // hittable.rs:26-29
+                normal = front_face ? outward : -outward;
+                m = mats[P.tm & 0x7fffffffu];
+                surface = true;
+            }
+        }
+        // Lambertian and Metal both start with Vec3::random_unit() (material.rs:36,69); its rejection loop is shared out
+        // over the wave (coop_reject): the lanes of both materials, and every other lane as a helper
+        const uint32_t path_lo = id % WH, path_hi = s_base + id / WH;
+        const bool wants_ru = surface && m.type != 2;
+        V3 ru = coop_reject<3>(wants_ru, (uint32_t)seed, (uint32_t)(seed >> 32), path_lo, path_hi, 1u + bounce, 0u, &s_coop[threadIdx.x >> 6]);
+        if (valid) {
+            if (surface) {
+                if (wants_ru) ru = ru / sqrt(length_squared(ru));      // vec3.rs:38
                 V3 attenuation; bool scattered;
-                // Lambertian and Metal both start with Vec3::random_unit() (material.rs:36,69): one rejection loop for the
-                // lanes of both, instead of one loop per material branch (the wave pays a loop's longest lane each time)
-                V3 ru = v3(0, 0, 0);
-                if (m.type != 2) ru = random_unit(g);
                 if (m.type == 0) {                                    // Lambertian material.rs:35-46
                     V3 sd = normal + ru;
                     if (near_zero(sd)) sd = normal;
@@ -703,6 +715,7 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
                     nd = reflected; attenuation = v3(m.albedo[0], m.albedo[1], m.albedo[2]);
                     scattered = dot(nd, normal) > 0.0;
                 } else {                                              // Dielectric material.rs:94-113
+                    Rng g(seed, path_lo, path_hi, 1u + bounce);
                     attenuation = v3(1.0, 1.0, 1.0);
                     double ri = front_face ? 1.0 / m.param : m.param;
                     V3 unit_direction = unit(d);
