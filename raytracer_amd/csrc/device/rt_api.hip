@@ -320,7 +320,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
-    if (const char* s = getenv("RT_STREAM_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_stream_blocks = (uint32_t)v; }
+    if (const char* s = getenv("RT_STREAM_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_stream_blocks = (uint32_t)v & ~7u; }
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
 #ifdef RT_STAMPS
     if (!g_dbg) { HIPCHECK(hipMalloc(&g_dbg, 16 * sizeof(unsigned long long))); HIPCHECK(hipMemset(g_dbg, 0, 16 * sizeof(unsigned long long))); }

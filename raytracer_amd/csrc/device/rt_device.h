@@ -130,6 +130,9 @@ RT_DEV V3 coop_reject(bool need, uint32_t k0, uint32_t k1, uint32_t lo, uint32_t
     bool undone = need;
     { V3 p; const bool acc = reject_item<DIM>(k0, k1, lo, hi, stream, base, 0, p); if (undone && acc) { res = p; undone = false; } }
     uint32_t next = 1;
+#ifdef RT_NO_COOP
+    while (undone) { V3 p; if (reject_item<DIM>(k0, k1, lo, hi, stream, base, next, p)) { res = p; undone = false; } ++next; }   // A/B only
+#endif
     for (;;) {
         const unsigned long long U = __builtin_amdgcn_ballot_w64(undone);
         if (U == 0) break;

@@ -4,7 +4,7 @@
 
 #define RT_BLOCK 128          // extend kernels: two wave64 per workgroup
 #ifndef RT_SBLOCK
-#define RT_SBLOCK 256
+#define RT_SBLOCK 512
 #endif                        // streaming kernels (generate, shade, accumulate): block-level queue compaction
 
 // SoA ray queue in HBM: one entry per live path (origin, direction, throughput, path id)
