@@ -322,46 +322,78 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     const uint32_t root_a = (root.b & RT_LEAF) ? root.a : root.a >> 1;       // internal: index of its children's pair
     const double scale = bvh.scale;
 
+    // Rays are taken from the queue 64 at a time into registers (lane i holds ray pf_base + i) while the wave is still
+    // traversing; idle lanes then pick theirs up with a lane permute.  A refill serves ~11 lanes: loading, dividing and
+    // testing the root box for just those would run at 17 % lane utilisation and stall the wave on HBM every time.
+    V3 P_o = v3(0, 0, 0), P_d = v3(1, 1, 1), P_inv = v3(1, 1, 1);
+    uint32_t pf_base = 0, pf_n = 0, pf_pos = 0;           // wave-uniform: the batch, and how much of it has been handed out
+    unsigned long long pf_hit = 0, pf_reg = 0;            // per batch ray: passed the root box / regular (see slab_fast_d)
+    bool pf_ready = true;
+    auto issue_batch = [&]() {
+        if (c_next >= c_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n) { exhausted = true; c_next = c_end = n; }
+            else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
+        }
+        pf_base = c_next; pf_n = (c_end - c_next < 64u) ? c_end - c_next : 64u; pf_pos = 0; c_next += pf_n;
+        if (lane < pf_n) {
+            const uint32_t pq = pf_base + lane;
+            P_o = v3(in.ox[pq], in.oy[pq], in.oz[pq]);
+            P_d = v3(in.dx[pq], in.dy[pq], in.dz[pq]);
+        }
+        pf_ready = pf_n == 0;
+    };
+
     for (;;) {
         // ---- refill idle lanes (looked at only after lanes have finished: nothing else changes the idle set)
         RT_STAMP(tk0 = clock64(); ++n_it;)
         if (look_for_rays) {
             const unsigned long long idle = ballot64(cur_b == RT_IDLE);
             const uint32_t n_idle = popc64(idle);
-            if (!exhausted && n_idle >= refill_min) {
+            if (!(exhausted && pf_pos >= pf_n) && n_idle >= refill_min) {
                 RT_STAMP(++n_ref;)
-                if (c_next >= c_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(fetch_ctr, chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n) { exhausted = true; c_next = c_end = n; }
-                    else { c_next = base; c_end = (n - base < chunk) ? n : base + chunk; }
-                }
-                const uint32_t avail = c_end - c_next;
-                const uint32_t rank = popc64(idle & ((1ull << lane) - 1ull));
-                if (cur_b == RT_IDLE && rank < avail) {
-                    q = c_next + rank;
-                    o = v3(in.ox[q], in.oy[q], in.oz[q]);
-                    d = v3(in.dx[q], in.dy[q], in.dz[q]);
-                    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                    regular = ray_is_regular(o, inv);
-                    rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-                    ++c_rays;
-                    tmax = tmax0; sp = 0; lo = 0; flag = false;
+                if (pf_pos >= pf_n) issue_batch();                       // first batch only: later ones are issued when the previous runs out
+                if (!pf_ready) {
+                    // finish the batch with all 64 lanes: 1/d, the root box test (bvh.rs:84-85, 182-185) and its misses' results
+                    const bool mine = lane < pf_n;
+                    P_inv = v3(1.0 / P_d.x, 1.0 / P_d.y, 1.0 / P_d.z);
                     double e0 = tmin0, e1 = tmax0;
-                    if (slab(root.mn, root.mx, o, inv, e0, e1)) { cur_a = root_a; cur_b = root.b; }   // bvh.rs:84-85
-                    else store_hit<SH_MODE>(out, q, false, rec, prims);
+                    const bool rh = mine && slab(root.mn, root.mx, P_o, P_inv, e0, e1);
+                    pf_hit = ballot64(rh);
+                    pf_reg = ballot64(mine && ray_is_regular(P_o, P_inv));
+                    if (mine) {
+                        ++c_rays;
+                        if (!rh) { HitState none; none.t = 0.0; none.tp = 0.0; none.tn = 0.0; none.prim = -1; store_hit<SH_MODE>(out, pf_base + lane, false, none, prims); }
+                    }
+                    pf_ready = true;
+                }
+                const uint32_t avail = pf_n - pf_pos;
+                const uint32_t rank = popc64(idle & ((1ull << lane) - 1ull));
+                const bool take = cur_b == RT_IDLE && rank < avail;
+                const uint32_t src = take ? pf_pos + rank : lane;
+                const V3 to = v3(__shfl(P_o.x, src, 64), __shfl(P_o.y, src, 64), __shfl(P_o.z, src, 64));
+                const V3 td = v3(__shfl(P_d.x, src, 64), __shfl(P_d.y, src, 64), __shfl(P_d.z, src, 64));
+                const V3 ti = v3(__shfl(P_inv.x, src, 64), __shfl(P_inv.y, src, 64), __shfl(P_inv.z, src, 64));
+                if (take) {
+                    q = pf_base + src; o = to; d = td; inv = ti;
+                    regular = (pf_reg >> src) & 1ull;
+                    rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+                    tmax = tmax0; sp = 0; lo = 0; flag = false;
+                    if ((pf_hit >> src) & 1ull) { cur_a = root_a; cur_b = root.b; }      // a root miss was answered when its batch was finished
                 }
                 const uint32_t taken = (n_idle < avail) ? n_idle : avail;
-                c_next += taken;
-                // a chunk that ran out mid-refill leaves lanes idle: look again next iteration (the next chunk is fetched then)
-                look_for_rays = !exhausted && taken < n_idle;
+                pf_pos += taken;
+                if (pf_pos >= pf_n && !exhausted) issue_batch();         // in flight while the wave traverses
+                // lanes are still idle if the batch ran out mid-refill or handed out root misses: look again next iteration
+                look_for_rays = !(exhausted && pf_pos >= pf_n) && ballot64(cur_b == RT_IDLE) != 0 && (taken < n_idle || ballot64(take && cur_b == RT_IDLE) != 0);
                 all_regular = ballot64(cur_b != RT_IDLE && !regular) == 0;     // min/max box test is exact only for regular rays
                 RT_STAMP(l_ref += taken; tk_ref += clock64() - tk0;)
             } else {
                 look_for_rays = false;
             }
-            if (ballot64(cur_b != RT_IDLE) == 0) { if (exhausted) break; look_for_rays = true; continue; }
+            if (ballot64(cur_b != RT_IDLE) == 0) { if (exhausted && pf_pos >= pf_n) break; look_for_rays = true; continue; }
         }
 
         // ---- phase vote.  A lane is either on an internal node (wants the two-box visit) or on a leaf / waiting
