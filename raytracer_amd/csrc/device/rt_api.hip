@@ -39,6 +39,7 @@ uint64_t g_batch_paths = 0;           // paths in flight per batch; 0 = size fro
 uint32_t g_tune = (8u << 16) | (1u << 8) | 1u;   // refill threshold | cost(internal) | cost(leaf) of the phase vote
 unsigned long long* g_dbg = nullptr;  // diagnostic builds (-DRT_STAMPS) only
 int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = persistent waves with dynamic refill
+int g_lg_samples = 7;                 // log2 of the samples of one pixel per generate wave; 7 = choose per batch (RT_LG_SAMPLES overrides)
 bool g_bounce_log = false;            // RT_BOUNCE_LOG=1: per-bounce kernel times on stderr while profiling is on
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 
@@ -256,7 +257,10 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         const uint32_t kb = (s_count - s0 < k) ? (s_count - s0) : k;
         HIPCHECK(hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st));
         begin_span(K_GENERATE);
-        hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, rb, s_begin + s0, kb, seed, w.q(0), w.counts, w.rad, (uint64_t)w.cap, w.stats);
+        // samples of a pixel per wave: the largest power of two (<= 64) that leaves at most 1/8 of the last group's lanes empty
+        uint32_t lg_s = g_lg_samples <= 6 ? (uint32_t)g_lg_samples : 6u;
+        if (g_lg_samples > 6) while (lg_s > 0 && (((kb + (1u << lg_s) - 1u) >> lg_s) << lg_s) - kb > kb / 8u) --lg_s;
+        hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, rb, s_begin + s0, kb, lg_s, seed, w.q(0), w.counts, w.rad, w.stats);
         end_span();
         for (uint32_t b = 0; b < max_depth; ++b) {
             ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.tn = sc->mixed ? w.hit_tn : nullptr; eo.hit = nullptr; eo.trace = 0;
@@ -266,7 +270,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             end_span(); ++extend_launches;
             begin_span(K_SHADE);
             hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
-                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint64_t)w.cap, (uint32_t)WH, s_begin + s0, b, max_depth, seed, w.stats);
+                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, kb, b, max_depth, seed, w.stats);
             end_span();
             HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
@@ -279,7 +283,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             if (*w.h_count == 0) break;
         }
         begin_span(K_RESOLVE);
-        hipLaunchKernelGGL(k_accumulate, sgrid, block, 0, st, w.rad, (uint64_t)w.cap, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
+        hipLaunchKernelGGL(k_accumulate, sgrid, block, 0, st, w.rad, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
         end_span();
         first = false;
     }
@@ -318,6 +322,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
+    if (const char* s = getenv("RT_LG_SAMPLES")) { int v = atoi(s); if (v >= 0 && v <= 7) g_lg_samples = v; }
     if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_STREAM_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_stream_blocks = (uint32_t)v & ~7u; }

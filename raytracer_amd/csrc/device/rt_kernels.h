@@ -31,8 +31,8 @@ struct DGrid {
 
 enum { ST_SCATTER = 0, ST_BOX, ST_PRIM, ST_STEPS, ST_OVERLAP, ST_GRIDBOX, ST_SEGMENTS, ST_N };
 
-__global__ void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t s_count, uint64_t seed, RayQ out, uint32_t* count_out,
-                           double* rad, uint64_t rad_stride, unsigned long long* stats);
+__global__ void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t s_count, uint32_t lg_s, uint64_t seed, RayQ out, uint32_t* count_out,
+                           double* rad, unsigned long long* stats);
 __global__ void k_generate_list(DCamera cam, uint32_t sample, uint64_t seed, const uint32_t* pi, const uint32_t* pj,
                                 uint64_t n, double* orig, double* dir);
 // DRAW = Options.draw_boxes (rtweekend.rs:92): the sticky rec.hits_aabb_edge of aabb.rs:57-60 is tracked per ray
@@ -53,7 +53,7 @@ __global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_shade(const DPrim* prims, const DMat* mats, RayQ in, const uint32_t* count_in,
                         const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,
-                        double* rad, uint64_t rad_stride, uint32_t WH, uint32_t s_base, uint32_t bounce, uint32_t max_depth, uint64_t seed,
+                        double* rad, uint32_t WH, uint32_t s_base, uint32_t s_count, uint32_t bounce, uint32_t max_depth, uint64_t seed,
                         unsigned long long* stats);
-__global__ void k_accumulate(const double* rad, uint64_t rad_stride, uint32_t WH, uint32_t s_count, double* fb, int first_batch);
+__global__ void k_accumulate(const double* rad, uint32_t WH, uint32_t s_count, double* fb, int first_batch);
 __global__ void k_load_rays(const double* orig, const double* dir, uint64_t n, RayQ q);

@@ -60,26 +60,32 @@ RT_DEV V3 sky_color(V3 d) {
 
 // ---------------------------------------------------------------------------------------------
 // generate: Camera::get_ray (camera.rs:132-148), sample_square (:189-191), defocus_disk_sample (:145-148).
-// One lane per (pixel, local sample); a wave covers an 8x8 pixel tile so primary rays stay coherent.
-// Path id = s_local * W*H + (j*W + i); RNG path = (j*W+i, s_base + s_local), stream 0.
+// One lane per (pixel, local sample).  A wave holds 2^lg_s samples of each pixel of a 2^lg_tw x 2^lg_th pixel tile
+// (lg_s + lg_tw + lg_th = 6; lane = sample * pixels + pixel): with 64 samples of ONE pixel per wave the lanes' primary
+// rays walk the same nodes and hit the same few triangles, and their scattered rays start next to each other, so the
+// extend kernel's lanes stay in step much longer than with an 8x8 tile of one sample.  Paths are what they were —
+// path id = s_local * W*H + (j*W + i); RNG path = (j*W+i, s_base + s_local), stream 0 — only their queue order changes.
 // With a BVH the root box test of the first world.hit (hittable_list.rs:84, bvh.rs:182-185) is done here: a primary ray
 // that misses it is a sky pixel sample (camera.rs:182-184) and never enters the queue (its box test is counted here).
-__global__ __launch_bounds__(RT_SBLOCK) void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t s_count, uint64_t seed,
-                                                        RayQ out, uint32_t* count_out, double* __restrict__ rad, uint64_t rad_stride,
+__global__ __launch_bounds__(RT_SBLOCK) void k_generate(DCamera cam, DRootBox root, uint32_t s_base, uint32_t s_count, uint32_t lg_s, uint64_t seed,
+                                                        RayQ out, uint32_t* count_out, double* __restrict__ rad,
                                                         unsigned long long* stats) {
     __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
     __shared__ CoopLds s_coop[RT_SBLOCK / 64];
     const uint32_t W = cam.W, H = cam.H;
-    const uint32_t tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
-    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y, n_waves = n_tiles * s_count;
+    const uint32_t lg_p = 6u - lg_s, lg_tw = (lg_p + 1u) >> 1, lg_th = lg_p >> 1;          // 64 = samples x tile width x tile height
+    const uint32_t tiles_x = (W + (1u << lg_tw) - 1u) >> lg_tw, tiles_y = (H + (1u << lg_th) - 1u) >> lg_th;
+    const uint32_t n_groups = (s_count + (1u << lg_s) - 1u) >> lg_s;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y, n_waves = n_tiles * n_groups;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = RT_SBLOCK / 64;
+    const uint32_t lp = lane & ((1u << lg_p) - 1u);                                        // pixel within the tile; lane >> lg_p = sample within the group
     uint64_t c_culled = 0;
     for (uint64_t wb = (uint64_t)blockIdx.x * wpb; wb < n_waves; wb += (uint64_t)gridDim.x * wpb) {
         const uint64_t w = wb + wave;
-        uint32_t s_local = (uint32_t)(w / n_tiles);
+        uint32_t s_local = ((uint32_t)(w / n_tiles) << lg_s) + (lane >> lg_p);
         uint32_t tile = (uint32_t)(w % n_tiles);
-        uint32_t i = (tile % tiles_x) * 8 + (lane & 7), j = (tile / tiles_x) * 8 + (lane >> 3);
-        bool valid = w < n_waves && i < W && j < H;
+        uint32_t i = ((tile % tiles_x) << lg_tw) + (lp & ((1u << lg_tw) - 1u)), j = ((tile / tiles_x) << lg_th) + (lp >> lg_tw);
+        bool valid = w < n_waves && i < W && j < H && s_local < s_count;
         V3 orig = v3(0, 0, 0), dir = v3(0, 0, 0);
         const uint32_t pix = j * W + i;
         const uint32_t id = s_local * (W * H) + pix;
@@ -101,7 +107,8 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_generate(DCamera cam, DRootBox ro
                 double e0 = 0.001, e1 = __builtin_huge_val();        // camera.rs:161
                 if (!slab(root.mn, root.mx, orig, inv, e0, e1)) {
                     V3 c = sky_color(dir);                            // throughput is (1,1,1)
-                    rad[id] = c.x; rad[rad_stride + id] = c.y; rad[2 * rad_stride + id] = c.z;
+                    double* slot = rad + ((uint64_t)pix * s_count + s_local) * 3u;   // rad[pixel][sample][rgb]: a wave's samples of a pixel are contiguous
+                    slot[0] = c.x; slot[1] = c.y; slot[2] = c.z;
                     valid = false; ++c_culled;
                 }
             }
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
                                                     RayQ in, const uint32_t* __restrict__ count_in,
                                                     const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
-                                                    double* __restrict__ rad, uint64_t rad_stride, uint32_t WH, uint32_t s_base,
+                                                    double* __restrict__ rad, uint32_t WH, uint32_t s_base, uint32_t s_count,
                                                     uint32_t bounce, uint32_t max_depth, uint64_t seed,
                                                     unsigned long long* stats) {
     __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
@@ -765,7 +772,8 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
                 }
             }
             if (!alive) {                                             // every path writes its slot exactly once
-                rad[id] = radiance.x; rad[rad_stride + id] = radiance.y; rad[2 * rad_stride + id] = radiance.z;
+                double* slot = rad + ((uint64_t)path_lo * s_count + id / WH) * 3u;   // one 24-byte record: a dead path's write touches one line, not three
+                slot[0] = radiance.x; slot[1] = radiance.y; slot[2] = radiance.z;
             }
         }
         uint32_t w = block_compact_slot(alive, count_out, s_tmp);
@@ -779,17 +787,16 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
     if (stats) stat_add(stats, ST_SCATTER, c_scatter);
 }
 
-// resolve: `pixel_color += ray_color(...)` (camera.rs:72) for the batch's samples, in sample order.
-__global__ __launch_bounds__(RT_SBLOCK) void k_accumulate(const double* __restrict__ rad, uint64_t rad_stride, uint32_t WH, uint32_t s_count,
+// resolve: `pixel_color += ray_color(...)` (camera.rs:72) for the batch's samples, in sample order.  One lane per pixel
+// walks that pixel's contiguous run of records (rad[pixel][sample][rgb]).
+__global__ __launch_bounds__(RT_SBLOCK) void k_accumulate(const double* __restrict__ rad, uint32_t WH, uint32_t s_count,
                                                           double* __restrict__ fb, int first_batch) {
     for (uint64_t p = (uint64_t)blockIdx.x * RT_SBLOCK + threadIdx.x; p < WH; p += (uint64_t)gridDim.x * RT_SBLOCK) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double acc = first_batch ? 0.0 : fb[p * 3 + c];
-            const double* plane = rad + (uint64_t)c * rad_stride + p;
-            for (uint32_t s = 0; s < s_count; ++s) acc = acc + plane[(uint64_t)s * WH];
-            fb[p * 3 + c] = acc;
-        }
+        double r = first_batch ? 0.0 : fb[p * 3], g = first_batch ? 0.0 : fb[p * 3 + 1], b = first_batch ? 0.0 : fb[p * 3 + 2];
+        const double* run = rad + p * s_count * 3u;
+#pragma unroll 4
+        for (uint32_t s = 0; s < s_count; ++s) { r = r + run[3 * s]; g = g + run[3 * s + 1]; b = b + run[3 * s + 2]; }
+        fb[p * 3] = r; fb[p * 3 + 1] = g; fb[p * 3 + 2] = b;
     }
 }
 
