@@ -299,8 +299,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     constexpr int SH_MODE = (TRACE ? 1 : 0) | (PRIMS != 0 ? 4 : 0);      // single-type scenes never read rec.tn
     const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu;
     const uint32_t refill_min = ((tune >> 16) & 0xffu) > 64u ? 64u : ((tune >> 16) & 0xffu);   // a fully idle wave always refills
-    __shared__ double s_fd[RT_STK][RT_BLOCK];
-    __shared__ uint2 s_ab[RT_STK][RT_BLOCK];
+    __shared__ uint4 s_stk[RT_STK][RT_BLOCK];       // {far_d lo, far_d hi, a, b | flag}: one 16-byte access per push / pop
     const uint32_t n = count ? *count : (uint32_t)n_fixed;
     const uint32_t T = gridDim.x * RT_BLOCK, tx = threadIdx.x, lane = tx & 63;
     StackEntry* my_spill = spill + (blockIdx.x * RT_BLOCK + tx);
@@ -443,13 +442,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 const bool go_right = rh && (!lh || ld >= rd); // bvh.rs:210-211 (tie -> right is `close`), :226-227; as lane-mask logic
                 if (both) {
                     if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
-                        StackEntry e; const uint32_t s = lo & (RT_STK - 1);
-                        e.far_d = s_fd[s][tx]; e.a = s_ab[s][tx].x; e.b = s_ab[s][tx].y;
-                        my_spill[(uint64_t)lo * T] = e; ++lo;
+                        *(uint4*)&my_spill[(uint64_t)lo * T] = s_stk[lo & (RT_STK - 1)][tx]; ++lo;     // same layout as StackEntry
                     }
-                    const uint32_t s = sp & (RT_STK - 1);
-                    s_fd[s][tx] = ld >= rd ? ld : rd;    // bvh.rs:212 f64::max of two non-NaN values
-                    s_ab[s][tx] = make_uint2(go_right ? La : Ra, (go_right ? Lb : Rb) | (flag ? 0x40000000u : 0u));
+                    const double far_d = ld >= rd ? ld : rd;    // bvh.rs:212 f64::max of two non-NaN values
+                    s_stk[sp & (RT_STK - 1)][tx] = make_uint4((uint32_t)__double2loint(far_d), (uint32_t)__double2hiint(far_d), go_right ? La : Ra,
+                                                              (go_right ? Lb : Rb) | (flag ? 0x40000000u : 0u));
                     ++sp; flag = false;
                 }
                 cur_a = go_right ? Ra : La;
@@ -498,10 +495,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 if (sp == 0) { done = true; cur_b = RT_IDLE; }
                 else {
                     --sp;
-                    const uint32_t s = sp & (RT_STK - 1);
-                    double far_d = s_fd[s][tx]; uint2 ab = s_ab[s][tx];
-                    asm volatile("" : "+v"(far_d), "+v"(ab.x), "+v"(ab.y));      // keep these as LDS reads (not a flat load of a selected pointer)
-                    if (sp < lo) { lo = sp; const StackEntry e = my_spill[(uint64_t)sp * T]; far_d = e.far_d; ab.x = e.a; ab.y = e.b; }
+                    uint4 se = s_stk[sp & (RT_STK - 1)][tx];
+                    asm volatile("" : "+v"(se.x), "+v"(se.y), "+v"(se.z), "+v"(se.w));      // keep this an LDS read (not a flat load of a selected pointer)
+                    if (sp < lo) { lo = sp; se = *(const uint4*)&my_spill[(uint64_t)sp * T]; }
+                    const double far_d = __hiloint2double((int)se.y, (int)se.x); uint2 ab = make_uint2(se.z, se.w);
                     const bool close_hit = flag;
                     flag = flag || ((ab.y >> 30) & 1u);
                     const bool overlap = close_hit && far_d < rec.t;      // bvh.rs:213-222
