@@ -491,6 +491,27 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 ++cur_a; --cur_b;                    // leaves hold >= 1 primitive (checked by rt_scene_set_bvh)
                 c_leaf += (cur_b == RT_POP) ? 1u : 0u;   // bvh.rs:190, once per leaf
             }
+            // one continuation: `far` is entered if `close` found nothing (bvh.rs:223) or its box starts before the hit (:213-222)
+            auto resume = [&](const uint4 se) {
+                const double far_d = __hiloint2double((int)se.y, (int)se.x);
+                const bool close_hit = flag;
+                flag = flag || ((se.w >> 30) & 1u);
+                const bool overlap = close_hit && far_d < rec.t;
+                if (overlap) { ++c_overlap; tmax = rec.t; }
+                if (overlap || !close_hit) { cur_a = se.z; cur_b = se.w & ~0x40000000u; }
+            };
+            // After a hit most pending far children lie behind it and are dropped one after the other; each drop used to be a
+            // loop iteration of the whole wave with an LDS round trip.  The top RT_POPW entries are read at once instead.
+            if (cur_b == RT_POP) {
+                uint4 w0 = s_stk[(sp - 1u) & (RT_STK - 1)][tx], w1 = s_stk[(sp - 2u) & (RT_STK - 1)][tx];
+                uint4 w2 = s_stk[(sp - 3u) & (RT_STK - 1)][tx], w3 = s_stk[(sp - 4u) & (RT_STK - 1)][tx];
+                asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w));
+                asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w));
+                if (sp > lo) { --sp; resume(w0); }                        // entries [lo, sp) are the ones in LDS
+                if (cur_b == RT_POP && sp > lo) { --sp; resume(w1); }
+                if (cur_b == RT_POP && sp > lo) { --sp; resume(w2); }
+                if (cur_b == RT_POP && sp > lo) { --sp; resume(w3); }
+            }
             while (cur_b == RT_POP) {
                 if (sp == 0) { done = true; cur_b = RT_IDLE; }
                 else {
@@ -498,12 +519,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     uint4 se = s_stk[sp & (RT_STK - 1)][tx];
                     asm volatile("" : "+v"(se.x), "+v"(se.y), "+v"(se.z), "+v"(se.w));      // keep this an LDS read (not a flat load of a selected pointer)
                     if (sp < lo) { lo = sp; se = *(const uint4*)&my_spill[(uint64_t)sp * T]; }
-                    const double far_d = __hiloint2double((int)se.y, (int)se.x); uint2 ab = make_uint2(se.z, se.w);
-                    const bool close_hit = flag;
-                    flag = flag || ((ab.y >> 30) & 1u);
-                    const bool overlap = close_hit && far_d < rec.t;      // bvh.rs:213-222
-                    if (overlap) { ++c_overlap; tmax = rec.t; }
-                    if (overlap || !close_hit) { cur_a = ab.x; cur_b = ab.y & ~0x40000000u; }   // :219 / :223
+                    resume(se);
                 }
             }
             if (done) store_hit<SH_MODE>(out, q, rec.prim >= 0, rec, prims);
