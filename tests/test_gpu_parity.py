@@ -165,6 +165,27 @@ def test_render_batching_does_not_change_the_image(gpu, monkeypatch):
     w.close()
 
 
+@pytest.mark.parametrize("scene,width,spp", [("simple_hollow_glass", 70, 13), ("dragon_res4", 61, 64), ("weekend-5-80-15", 48, 100)])
+def test_queue_order_does_not_change_the_image(gpu, monkeypatch, scene, width, spp):
+    """k_generate may put 1, 4, 16 or 64 samples of a pixel into one wave (RT_LG_SAMPLES) and the streaming kernels may run
+    on any grid (RT_STREAM_BLOCKS): paths land in the queues in a different order, every path and the ordered per-pixel
+    sum stay what they were, so the framebuffer and the counters are bit-identical.  Odd sizes: partial tiles and groups."""
+    import raytracer_amd as rt
+    w = load_world(scene); w.algorithm = "bvh"; w.init(); w.upload()
+    cam = Camera(w.filename, image_width=width, samples_per_pixel=spp)
+    ref = None
+    try:
+        for lg, blocks in (("7", "4096"), ("0", "4096"), ("2", "64"), ("4", "4096"), ("6", "8")):
+            monkeypatch.setenv("RT_LG_SAMPLES", lg); monkeypatch.setenv("RT_STREAM_BLOCKS", blocks); rt.init(0)
+            img, st = cam.render(w, seed=5)
+            key = (img.tobytes(), st["scatter_rays"], st["intersection_checks"], st["traversal_steps"], st["overlapping_aabb"])
+            if ref is None: ref = key
+            assert key == ref, f"RT_LG_SAMPLES={lg} RT_STREAM_BLOCKS={blocks}"
+    finally:
+        monkeypatch.setenv("RT_LG_SAMPLES", "7"); monkeypatch.setenv("RT_STREAM_BLOCKS", "4096"); rt.init(0)     # the library's defaults
+    w.close()
+
+
 def test_full_size_properties_weekend_final(gpu):
     """configs[1] at full size (1920x1080; 2 of the 256 spp): size-independent properties only —
     exact primary count, finite non-negative radiance bounded by the sky colour, and the image of samples
