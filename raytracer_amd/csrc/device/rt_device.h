@@ -43,8 +43,8 @@ RT_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         if (r) { k0 += W0; k1 += W1; }
-        uint32_t h0 = __umulhi(M0, c[0]), l0 = M0 * c[0];
-        uint32_t h1 = __umulhi(M1, c[2]), l1 = M1 * c[2];
+        const uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];      // one v_mad_u64_u32 each instead of mul_hi + mul_lo
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
         c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
     }
