@@ -804,7 +804,7 @@ __global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ p
 // walks that pixel's contiguous run of records (rad[pixel][sample][rgb]).
 __global__ __launch_bounds__(RT_SBLOCK) void k_accumulate(const double* __restrict__ rad, uint32_t WH, uint32_t s_count,
                                                           double* __restrict__ fb, int first_batch) {
-    for (uint64_t p = (uint64_t)blockIdx.x * RT_SBLOCK + threadIdx.x; p < WH; p += (uint64_t)gridDim.x * RT_SBLOCK) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < WH; p += (uint64_t)gridDim.x * blockDim.x) {
         double r = first_batch ? 0.0 : fb[p * 3], g = first_batch ? 0.0 : fb[p * 3 + 1], b = first_batch ? 0.0 : fb[p * 3 + 2];
         const double* run = rad + p * s_count * 3u;
 #pragma unroll 4
