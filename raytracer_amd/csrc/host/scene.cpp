@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <thread>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -206,6 +207,77 @@ double read_bin(const unsigned char* p, const std::string& t, bool big) {
     if (t == "float" || t == "float32") { float v; memcpy(&v, b, 4); return v; }
     double v; memcpy(&v, b, 8); return v;
 }
+
+struct Fact { int coord; bool f32, is_idx; };        // what a PLY property means to the loader: x/y/z, float typed, the index list
+
+size_t ply_parallel_min() {                          // rows from which an ASCII element is parsed by several threads (RT_PLY_PAR_MIN)
+    const char* e = getenv("RT_PLY_PAR_MIN");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)65536;
+}
+
+// Rows [0, count) of an ASCII element, one row per line, parsed by up to 16 threads.  Vertex rows fill `verts` (appended),
+// face rows append triangles to `out`.  Returns false (and appends nothing) unless every row parsed cleanly.
+bool parse_rows_parallel(const char* cur, const char* end, size_t count, const Fact* facts, const char* is_list, size_t n_props, bool is_v,
+                         std::vector<double>& verts, Scene& out, const char*& after) {
+    std::vector<const char*> line(count + 1);
+    const char* p = cur;
+    for (size_t r = 0; r < count; ++r) {
+        line[r] = p;
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) { if (r + 1 != count || p >= end) return false; p = end; } else p = nl + 1;
+    }
+    line[count] = p;
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 16) nt = 16;
+    if (const char* e = getenv("RT_PLY_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nt = (unsigned)v; }
+    const size_t v0 = verts.size(), n_verts = v0 / 3, p0 = out.prims.size();
+    if (is_v) verts.resize(v0 + count * 3); else { out.prims.resize(p0 + count); out.centroids.resize((p0 + count) * 3); }
+    std::vector<char> bad(nt, 0);
+    auto work = [&](unsigned t) {
+        const size_t a = count * t / nt, b = count * (t + 1) / nt;
+        for (size_t r = a; r < b; ++r) {
+            const char* c = line[r]; const char* e = line[r + 1];
+            auto tok = [&](const char*& tb) { while (c < e && (*c == ' ' || *c == '\t' || *c == '\r' || *c == '\n')) ++c; if (c >= e) return false; tb = c; while (c < e && !(*c == ' ' || *c == '\t' || *c == '\r' || *c == '\n')) ++c; return true; };
+            double xyz[3] = {0, 0, 0}; bool got[3] = {false, false, false}; int64_t idx[3] = {0, 0, 0}; bool got_idx = false;
+            for (size_t pi = 0; pi < n_props; ++pi) {
+                size_t n = 1; const char* tb;
+                if (is_list[pi]) { int64_t nv; if (!tok(tb) || !parse_int(tb, nv) || nv < 0 || nv > 64) { bad[t] = 1; return; } n = (size_t)nv; }
+                if (!is_v && is_list[pi] && facts[pi].is_idx && n != 3) { bad[t] = 1; return; }
+                for (size_t k = 0; k < n; ++k) {
+                    if (!tok(tb)) { bad[t] = 1; return; }
+                    if (is_v && !is_list[pi] && facts[pi].coord >= 0) {
+                        if (!facts[pi].f32) { bad[t] = 1; return; }
+                        xyz[facts[pi].coord] = (double)parse_f32(tb) * 100.0; got[facts[pi].coord] = true;       // parser.rs:67-73
+                    } else if (!is_v && is_list[pi] && facts[pi].is_idx) {
+                        int64_t iv; if (facts[pi].f32 || !parse_int(tb, iv)) { bad[t] = 1; return; }
+                        idx[k] = iv; got_idx = true;
+                    }
+                }
+            }
+            const char* tb; if (tok(tb)) { bad[t] = 1; return; }                    // more tokens on the line than the header declares
+            if (is_v) {
+                if (!got[0] || !got[1] || !got[2]) { bad[t] = 1; return; }
+                for (int k = 0; k < 3; ++k) verts[v0 + 3 * r + k] = xyz[k];
+            } else {
+                if (!got_idx) { bad[t] = 1; return; }
+                rt_prim q; memset(&q, 0, sizeof q); q.type = RT_TRIANGLE; q.material = 0;
+                for (int k = 0; k < 3; ++k) {
+                    if (idx[k] < 0 || (size_t)idx[k] >= n_verts) { bad[t] = 1; return; }
+                    for (int cc = 0; cc < 3; ++cc) q.v[3 * k + cc] = verts[(size_t)idx[k] * 3 + cc];
+                }
+                out.prims[p0 + r] = q;
+                for (int k = 0; k < 3; ++k) out.centroids[3 * (p0 + r) + k] = (q.v[k] + q.v[3 + k] + q.v[6 + k]) / 3.0;   // Triangle::new triangle.rs:21-28
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    bool ok = true; for (char b2 : bad) ok = ok && !b2;
+    if (!ok) { if (is_v) verts.resize(v0); else { out.prims.resize(p0); out.centroids.resize(p0 * 3); } return false; }
+    after = line[count];
+    return true;
+}
 } // namespace
 
 bool load_ply(const std::string& path, const rt_material& mat, Scene& out, std::string& err) {
@@ -255,12 +327,22 @@ bool load_ply(const std::string& path, const rt_material& mat, Scene& out, std::
     for (const PlyElem& el : elems) {
         const bool is_v = el.name == "vertex", is_f = el.name == "face";
         // per-property facts, looked up once per element instead of once per value
-        struct Fact { int coord; bool f32, is_idx; }; std::vector<Fact> facts;
+        std::vector<Fact> facts;
         for (const PlyProp& pr : el.props)
             facts.push_back({pr.name == "x" ? 0 : (pr.name == "y" ? 1 : (pr.name == "z" ? 2 : -1)), is_float_type(pr.type), pr.name == "vertex_indices"});
         if (is_v) { have_v = true; verts.reserve(el.count * 3); }
         if (is_f) { have_f = true; if (!have_v) { err = "Parse error No vertices in PLY file"; return false; } out.prims.reserve(el.count); out.centroids.reserve(el.count * 3); }
-        for (size_t r = 0; r < el.count; ++r) {
+        size_t r_begin = 0;
+        if (fmt == 0 && (is_v || is_f) && el.count >= ply_parallel_min()) {
+            // Big ASCII elements (the 871 k-triangle dragon is 1.3 M lines): rows are split over threads at line starts.
+            // Anything unusual (a row that is not exactly one line, a bad token, an index out of range) makes this
+            // return false with nothing consumed, and the token-by-token loop below parses — and reports — as it always did.
+            std::vector<Fact> fv(facts.begin(), facts.end());
+            std::vector<char> is_list; for (const PlyProp& pr : el.props) is_list.push_back(pr.is_list ? 1 : 0);
+            const char* after = nullptr;
+            if (parse_rows_parallel(cur, end, el.count, fv.data(), is_list.data(), fv.size(), is_v, verts, out, after)) { cur = after; r_begin = el.count; }
+        }
+        for (size_t r = r_begin; r < el.count; ++r) {
             double xyz[3] = {0, 0, 0}; bool got[3] = {false, false, false};
             idx.clear(); bool got_idx = false;
             for (size_t pi = 0; pi < el.props.size(); ++pi) {

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import _ffi as F
-from raytracer_amd import Camera, HittableList
+from raytracer_amd import Camera, HittableList, RtError
 
 from .util import load_world, oracle_of, weekend_mixed
 
@@ -212,3 +212,78 @@ def test_ply_float_parser_is_correctly_rounded(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Iinclude", "-o", exe, "tests/native/parse_f32_check.cpp"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-500:]
+
+
+def _write_ascii_ply(path, verts, faces, extra_vertex_props=0, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        f.write("ply" + nl + "format ascii 1.0" + nl + f"element vertex {len(verts)}" + nl)
+        f.write("property float x" + nl + "property float y" + nl + "property float z" + nl)
+        for k in range(extra_vertex_props):
+            f.write(f"property float extra{k}" + nl)
+        f.write(f"element face {len(faces)}" + nl + "property list uchar int vertex_indices" + nl + "end_header" + nl)
+        tail = "".join(" 0.5" for _ in range(extra_vertex_props))
+        f.write(nl.join(f"{np.float32(x):.9g} {np.float32(y):.9g}  {np.float32(z):.9g}{tail} " for x, y, z in verts) + nl)
+        f.write(nl.join(f"3 {a} {b} {c} " for a, b, c in faces) + nl)
+
+
+def test_parallel_ply_parse_equals_the_token_parser(tmp_path, monkeypatch):
+    """big ASCII elements are parsed by several threads, rows split at line starts; the result must be
+    the token-by-token parser's, and anything that is not one-row-per-line falls back to it (same errors)."""
+    rng = np.random.default_rng(9)
+    nv, nf = 5000, 9000
+    verts = (rng.normal(size=(nv, 3)) * [0.1, 0.07, 0.05] + [0, 0.12, 0]).astype(np.float32)
+    verts[:7] = [[0, 0, 0], [1e-30, -1e-30, 3.4e38], [0.1, 0.2, 0.3], [-0.0, 1, 2], [1.17549435e-38, 5e-39, 1e-45], [16777217, 0.30000001192092896, 1e10], [7, 8, 9]]
+    faces = rng.integers(0, nv, size=(nf, 3))
+
+    def load(path, par):
+        monkeypatch.setenv("RT_PLY_PAR_MIN", "0" if par else "18446744073709551615")
+        w = HittableList.from_ply(str(path))
+        return w.prims().tobytes(), w.centroids().tobytes()
+
+    for extra, crlf in ((0, False), (2, False), (1, True)):
+        path = tmp_path / f"m{extra}{int(crlf)}.ply"
+        _write_ascii_ply(path, verts, faces, extra, crlf)
+        monkeypatch.setenv("RT_PLY_THREADS", "5")
+        assert load(path, True) == load(path, False)
+    # the reference's own mesh
+    ref = "scenes/dragon_recon/dragon_vrip_res4.ply"
+    assert load(ref, True) == load(ref, False)
+    # rows that span lines, a short face row and an out-of-range index: the thread path declines, the token parser decides
+    good = open(tmp_path / "m00.ply").read()
+    head, body = good.split("end_header\n")
+    lines = body.split("\n")
+    spanning = head + "end_header\n" + "\n".join([lines[0].replace(" ", "\n", 1)] + lines[1:])
+    (tmp_path / "span.ply").write_text(spanning)
+    assert load(tmp_path / "span.ply", True) == load(tmp_path / "m00.ply", False)
+    bad_idx = head + "end_header\n" + "\n".join(lines[:nv] + [f"3 0 1 {nv}"] + lines[nv + 1:])
+    (tmp_path / "bad.ply").write_text(bad_idx)
+    msgs = []
+    for par in (True, False):
+        with pytest.raises(RtError) as e:
+            load(tmp_path / "bad.ply", par)
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "not found" in msgs[0]
+
+
+def test_parallel_ply_parse_time_on_a_full_size_mesh(tmp_path, monkeypatch):
+    """A 765 k-triangle ASCII PLY (the bench mesh written out; the reference's full dragon is 871 k): both parsers agree; times printed."""
+    import time
+    w = HittableList.from_ply("scenes/dragon_recon/dragon_vrip_res3.ply", subdivide=2)
+    tri = w.prims()["v"].reshape(-1, 3, 3) / 100.0
+    verts, inv = np.unique(tri.reshape(-1, 3), axis=0, return_inverse=True)
+    faces = inv.reshape(-1, 3)
+    path = tmp_path / "big.ply"
+    with open(path, "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\nproperty float z\n"
+                f"element face {len(faces)}\nproperty list uchar int vertex_indices\nend_header\n")
+        np.savetxt(f, verts.astype(np.float32), fmt="%.9g")
+        np.savetxt(f, np.hstack([np.full((len(faces), 1), 3), faces]), fmt="%d")
+    out = {}
+    for par in (False, True):
+        monkeypatch.setenv("RT_PLY_PAR_MIN", "0" if par else "18446744073709551615")
+        t = time.time(); m = HittableList.from_ply(str(path)); dt = time.time() - t
+        out[par] = (m.prims().tobytes(), dt)
+    assert out[True][0] == out[False][0] and len(out[True][0]) == len(faces) * 80
+    assert np.array_equal(np.frombuffer(out[True][0], dtype=w.prims().dtype)["v"], w.prims()["v"])       # and it is the mesh that was written
+    print(f"\nASCII PLY, {len(faces)} faces, {os.path.getsize(path) >> 20} MiB: token parser {out[False][1]:.2f} s, threads {out[True][1]:.2f} s")
