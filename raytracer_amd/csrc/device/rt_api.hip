@@ -149,8 +149,12 @@ int ensure_workspace(rt_scene* sc, uint64_t cap, uint32_t depth_cap) {
 }
 
 int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* count, uint64_t n_fixed, double tmin, double tmax,
-                  const ExtendOut& out, uint32_t* fetch_ctr, hipStream_t st) {
-    dim3 grid(g_extend_blocks), block(RT_BLOCK);
+                  const ExtendOut& out, uint32_t* fetch_ctr, hipStream_t st, uint64_t n_hint = 0) {
+    // n_hint = queue length when the host knows it (0: unknown): a short queue gets a grid of one lane per ray instead of 4096
+    // waves that each pay an atomic on the fetch counter to learn that nothing is left (88 per microsecond on one word)
+    uint32_t nblk = g_extend_blocks;
+    if (n_hint) { const uint64_t want = ((n_hint + RT_BLOCK - 1) / RT_BLOCK + 7) & ~7ull; if (want < nblk) nblk = (uint32_t)want; }
+    dim3 grid(nblk), block(RT_BLOCK);
     switch (algorithm) {
     case RT_ALGO_BVH:
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
@@ -265,10 +269,11 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         if (g_lg_samples > 6) while (lg_s > 0 && (((kb + (1u << lg_s) - 1u) >> lg_s) << lg_s) - kb > kb / 8u) --lg_s;
         hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, rb, s_begin + s0, kb, lg_s, seed, w.q(0), w.counts, w.rad, w.stats);
         end_span();
+        uint64_t n_known = 0;                                             // the next queue's length, once a bounce has reported it
         for (uint32_t b = 0; b < max_depth; ++b) {
             ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.tn = sc->mixed ? w.hit_tn : nullptr; eo.hit = nullptr; eo.trace = 0;
             begin_span(K_EXTEND);
-            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, w.counts + w.depth_cap + b, st);
+            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, w.counts + w.depth_cap + b, st, n_known);
             if (rc) return rc;
             end_span(); ++extend_launches;
             begin_span(K_SHADE);
@@ -284,6 +289,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             }
             if (g_profiling) drain_spans();
             if (*w.h_count == 0) break;
+            n_known = *w.h_count;
         }
         begin_span(K_RESOLVE);
         hipLaunchKernelGGL(k_accumulate, dim3(g_acc_blocks), dim3(g_acc_threads), 0, st, w.rad, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
@@ -616,7 +622,7 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
         hipLaunchKernelGGL(k_load_rays, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_o, d_d, m, w.q(0));
         ExtendOut eo; eo.prim = w.hit_prim; eo.t = d_t; eo.tp = w.hit_tp; eo.tn = nullptr; eo.hit = d_h; eo.trace = 1;
         if (hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st) != hipSuccess) { ret = fail(RT_E_HIP, "memset failed"); break; }
-        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, w.counts + w.depth_cap, st);
+        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, w.counts + w.depth_cap, st, m);
         if (ret) break;
         if (out_prim) e = hipMemcpyAsync(out_prim + off, w.hit_prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && out_t) e = hipMemcpyAsync(out_t + off, d_t, m * sizeof(double), hipMemcpyDeviceToHost, st);
