@@ -687,6 +687,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
 template __global__ void k_extend_grid<false>(DGrid, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
 template __global__ void k_extend_grid<true>(DGrid, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
 
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 6      // 80 VGPRs: three 512-thread blocks per CU instead of two (shade 59 -> 56.5 ms; 8 spills and is slower)
+#endif
 // ---------------------------------------------------------------------------------------------
 // shade: the body of ray_color after world.hit (camera.rs:161-185) for one bounce, iteratively:
 //   miss            -> radiance = throughput * sky (camera.rs:182-184), path ends
@@ -698,7 +701,7 @@ template __global__ void k_extend_grid<true>(DGrid, const DPrim*, RayQ, const ui
 // normal and front_face as sphere.rs:51-52 / triangle.rs:39-41,77 compute them.
 // The throughput is a left-to-right product where the reference nests right-to-left (camera.rs:172):
 // radiance may differ from the reference's in the last ulps; hit/miss decisions are unaffected.
-__global__ __launch_bounds__(RT_SBLOCK) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
+__global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
                                                     RayQ in, const uint32_t* __restrict__ count_in,
                                                     const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
