@@ -16,7 +16,7 @@ bench = json.loads([l for l in open(f"{d}/trace.log") if l.startswith('{"metric"
 rows = list(csv.DictReader(open(src)))
 md = [f"# `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` ({tag})\n",
       f"bench line of the same run: {bench['value']:.1f} Mrays/s, {bench['ms_per_step']:.1f} ms/step; HIP-event extend avg launch "
-      f"{bench['roofline']['avg_launch_ms']:.3f} ms over {bench["roofline"]["launches"]} launches in the timed steps\n",
+      f"{bench['roofline']['avg_launch_ms']:.3f} ms over {bench['roofline']['launches']} launches in the timed steps\n",
       "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
 for r in rows:
     md.append(f"| {r['Name'][:70]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
