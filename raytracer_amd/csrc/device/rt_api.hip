@@ -277,7 +277,7 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
             if (rc) return rc;
             end_span(); ++extend_launches;
             begin_span(K_SHADE);
-            hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
+            hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, sc->n_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
                                w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, kb, b, max_depth, seed, w.stats);
             end_span();
             HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -51,7 +51,7 @@ __global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, co
 template <bool DRAW>
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
-__global__ void k_shade(const DPrim* prims, const DMat* mats, RayQ in, const uint32_t* count_in,
+__global__ void k_shade(const DPrim* prims, const DMat* mats, uint32_t n_mats, RayQ in, const uint32_t* count_in,
                         const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,
                         double* rad, uint32_t WH, uint32_t s_base, uint32_t s_count, uint32_t bounce, uint32_t max_depth, uint64_t seed,
                         unsigned long long* stats);

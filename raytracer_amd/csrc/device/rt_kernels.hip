@@ -701,7 +701,8 @@ template __global__ void k_extend_grid<true>(DGrid, const DPrim*, RayQ, const ui
 // normal and front_face as sphere.rs:51-52 / triangle.rs:39-41,77 compute them.
 // The throughput is a left-to-right product where the reference nests right-to-left (camera.rs:172):
 // radiance may differ from the reference's in the last ulps; hit/miss decisions are unaffected.
-__global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats,
+#define RT_SHADE_LDS_MATS 512      // materials kept in LDS (20 KB): the third dependent global load of a shade (ray -> primitive -> material) becomes an LDS read
+__global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats, uint32_t n_mats,
                                                     RayQ in, const uint32_t* __restrict__ count_in,
                                                     const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
@@ -710,6 +711,9 @@ __global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim
                                                     unsigned long long* stats) {
     __shared__ uint32_t s_tmp[RT_SBLOCK / 64];
     __shared__ CoopLds s_coop[RT_SBLOCK / 64];
+    __shared__ DMat s_mats[RT_SHADE_LDS_MATS];
+    const bool mats_lds = n_mats <= RT_SHADE_LDS_MATS;
+    if (mats_lds) { for (uint32_t i = threadIdx.x; i < n_mats; i += RT_SBLOCK) s_mats[i] = mats[i]; __syncthreads(); }
     const uint64_t n = (uint64_t)*count_in;
     const uint64_t T = (uint64_t)gridDim.x * RT_SBLOCK;
     uint64_t c_scatter = 0;
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim
                 }
                 front_face = dot(d, outward) < 0.0;                   // hittable.rs:26-29
                 normal = front_face ? outward : -outward;
-                m = mats[P.tm & 0x7fffffffu];
+                m = mats_lds ? s_mats[P.tm & 0x7fffffffu] : mats[P.tm & 0x7fffffffu];
                 surface = true;
             }
         }
