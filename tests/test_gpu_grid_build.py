@@ -67,3 +67,14 @@ def test_gpu_grid_full_size_mesh_and_time(gpu):
     compare(w, 1.0)                                   # first call pays hipCUB kernel loading
     t_dev = compare(w, 1.0)
     print(f"\ngrid build (size 1), 764704 triangles: host {t_host:.2f} s, GPU {t_dev:.3f} s")
+
+
+@pytest.mark.parametrize("n", [0, 1])
+def test_gpu_grid_of_an_empty_and_a_one_object_scene(gpu, n):
+    pd = np.dtype([("type", "<u4"), ("material", "<u4"), ("v", "<f8", (9,))])
+    md = np.dtype([("type", "<u4"), ("pad", "<u4"), ("albedo", "<f8", (3,)), ("param", "<f8")])
+    p = np.zeros(n, pd)
+    if n:
+        p["v"][0, :4] = (0, 0, -1, 0.5)
+    w = HittableList.from_arrays(p, np.zeros((n, 3)), np.zeros(1, md))
+    compare(w, 25)
