@@ -211,6 +211,14 @@ def test_errors_are_reported_not_crashed(gpu):
     with pytest.raises(RtError):
         w.hit(np.zeros((1, 3)), np.ones((1, 3)), algorithm="grid")
     assert w.hit(np.zeros((0, 3)), np.zeros((0, 3)), algorithm="naive")["prim"].shape == (0,)
+    with pytest.raises(RtError, match="no grid"):
+        w.device_grid()                                                  # rt_scene_get_grid before any grid was installed
+    with pytest.raises(RtError, match="grid size"):
+        w.build_grid_on_device(0.5)                                      # grid.rs:36 step_by(0) panics in the reference
+    with pytest.raises(RtError):
+        w.build_grid_on_device(float("nan"))
+    w.build_grid_on_device(25.0)
+    assert w.device_grid()[0].n_cells == 512 and w.hit(np.zeros((1, 3)), np.ones((1, 3)), algorithm="grid")["prim"].shape == (1,)
     w.close()
 
 
