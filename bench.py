@@ -135,6 +135,7 @@ def main():
         pair_b, prim_b = w.bvh_layout()                         # what the kernel's layout for this scene really reads
         layout_bytes = 60.0 * seg + 0.5 * pair_b * nbox + prim_b * nprim
         pmc = pmc_figures()
+        lane_acc = ((pair_b / 16.0) * 0.5 * nbox + (prim_b / 16.0) * nprim + 6.0 * seg) / ext_s / (256 * 2.4e9) if ext_s > 0 else 0.0
         out = {
             "metric": "Mrays/s (whole node) dragon PLY BVH; PSNR vs CPU render checked in tests",
             "value": total_rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -156,7 +157,10 @@ def main():
                          "layout": {"pair_bytes": pair_b, "prim_bytes": prim_b, "requested_GBps": layout_bytes / ext_s / 1e9 if ext_s > 0 else 0.0},
                          # what actually bounds it: divergent 16-B lane accesses at ~1 per clock per CU in the vector L1,
                          # and VALU issue; figures from the committed PMC passes of the same kernel, not from this run
-                         "lane_accesses_per_clk_per_cu": ((pair_b / 16.0) * 0.5 * nbox + (prim_b / 16.0) * nprim + 6.0 * seg) / ext_s / (256 * 2.4e9) if ext_s > 0 else 0.0,
+                         "lane_accesses_per_clk_per_cu": lane_acc,
+                         # what actually bounds this kernel: divergent <=16-B lane accesses per clock per CU against the
+                         # 1.1 measured in a pure gather (tools/mb/mb_gather.hip, profiles/round1_mb_gather.txt)
+                         "l1_lane_access_bound": {"achieved": lane_acc, "peak": 1.1, "unit": "lane accesses/clk/CU", "frac": lane_acc / 1.1},
                          "pmc": pmc},
         }
         if world == 1 and not a.no_cpu_baseline:
