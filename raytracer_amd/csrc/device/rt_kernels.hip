@@ -23,17 +23,6 @@ RT_DEV void stat_add(unsigned long long* stats, int slot, uint64_t v) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[slot], (unsigned long long)v);
 }
-// wave64 compaction: returns the output index for lanes with `alive`, one atomic per wave
-RT_DEV uint32_t compact_slot(bool alive, uint32_t* counter) {
-    unsigned long long mask = __ballot(alive);
-    uint32_t lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    int leader = __ffsll((long long)mask) - 1;
-    if (alive && (int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader < 0 ? 0 : leader, 64);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
 // block-level compaction: one atomic per workgroup (a single counter word saturates near 88 atomics/us, so one
 // atomic per wave makes a 10^8-path launch atomic-bound).  Every thread of the block must call it, the same number of times.
 RT_DEV uint32_t block_compact_slot(bool alive, uint32_t* counter, uint32_t* s_tmp /* [blockDim.x/64] */) {
@@ -696,7 +685,7 @@ template __global__ void k_extend_grid<true>(DGrid, const DPrim*, RayQ, const ui
 //   hit, no scatter -> radiance = 0 (camera.rs:176), path ends
 //   hit, scatter    -> scatter_rays++ (camera.rs:171); throughput *= attenuation; if this was the last
 //                      allowed bounce the child call returns black (camera.rs:155-157), else the scattered
-//                      ray is appended to the next queue (wave ballot + prefix sum, one atomic per wave).
+//                      ray is appended to the next queue (wave ballots + a prefix sum over the workgroup, one atomic per 512 threads).
 // The hit record is rebuilt from (prim, tp): rec.p = at(tp) (sphere.rs:50, triangle.rs:59), the outward
 // normal and front_face as sphere.rs:51-52 / triangle.rs:39-41,77 compute them.
 // The throughput is a left-to-right product where the reference nests right-to-left (camera.rs:172):
