@@ -270,6 +270,36 @@ RT_DEV bool hit_triangle_flat(const DPrim& tr, int32_t index, V3 o, V3 d, double
 RT_DEV bool hit_prim_flat(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
     return (p.tm >> 31) ? hit_triangle_flat(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
 }
+// Triangle::hit with the ray-independent part hoisted: n = (v1-v0)x(v2-v0) (triangle.rs:39-41) and d = -n.v0 (:50) are pure
+// functions of the triangle, computed once per scene by k_tri_pre with the very expressions hit_triangle uses, so every value
+// is the one the reference recomputes per test.  The naive and grid walks test hundreds to thousands of triangles per ray and
+// half of them leave at the n.dir test (:44-47): those now cost one 32-byte read and a dot product, and never touch the vertices.
+struct __align__(16) DTriPre { double n[3]; double dd; };
+RT_DEV bool hit_triangle_pre(const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre, uint32_t pi, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    const DTriPre q = pre[pi];
+    const V3 n = v3(q.n[0], q.n[1], q.n[2]);
+    double n_dot_dir = dot(n, d);
+    if (!(tmin < n_dot_dir && n_dot_dir < tmax)) return false;
+    double t = -(dot(n, o) + q.dd) / n_dot_dir;
+    rec.t = t;
+    if (t < 0.0) return false;
+    rec.tp = t;
+    const DPrim tr = prims[pi];
+    V3 v0 = v3(tr.v[0], tr.v[1], tr.v[2]), v1 = v3(tr.v[3], tr.v[4], tr.v[5]), v2 = v3(tr.v[6], tr.v[7], tr.v[8]);
+    V3 p = o + (t * d);
+    V3 v0v1 = v1 - v0;
+    V3 v0p = p - v0;
+    if (dot(n, cross(v0v1, v0p)) <= 0.0) return false;
+    V3 v1v2 = v2 - v1;
+    V3 v1p = p - v1;
+    if (dot(n, cross(v1v2, v1p)) <= 0.0) return false;
+    V3 v2v0 = v0 - v2;
+    V3 v2p = p - v2;
+    if (dot(n, cross(v2v0, v2p)) <= 0.0) return false;
+    rec.prim = (int32_t)pi; rec.tn = t;
+    return true;
+}
+
 RT_DEV bool hit_prim(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
     return (p.tm >> 31) ? hit_triangle(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
 }

@@ -46,10 +46,11 @@ struct BvhView { const DNode* nodes; const DPrim* prims; const DPair64* pairs64;
 template <int NODES, int PRIMS, bool TRACE>
 __global__ void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
-__global__ void k_extend_naive(const DPrim* prims, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
+__global__ void k_tri_pre(const DPrim* prims, uint32_t n, DTriPre* pre);
+__global__ void k_extend_naive(const DPrim* prims, const DTriPre* pre, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                                double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 template <bool DRAW>
-__global__ void k_extend_grid(DGrid g, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
+__global__ void k_extend_grid(DGrid g, const DPrim* prims, const DTriPre* pre, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_shade(const DPrim* prims, const DMat* mats, uint32_t n_mats, RayQ in, const uint32_t* count_in,
                         const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,

@@ -531,7 +531,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
 RT_INST_BVH2(0, 0, false) RT_INST_BVH2(0, 0, true) RT_INST_BVH2(0, 2, false) RT_INST_BVH2(0, 2, true) RT_INST_BVH2(1, 1, false) RT_INST_BVH2(1, 1, true)
 
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, uint32_t n_prims,
+// per-triangle constants of hit_triangle_pre (all-triangle scenes only)
+__global__ void k_tri_pre(const DPrim* __restrict__ prims, uint32_t n, DTriPre* __restrict__ pre) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DPrim tr = prims[i];
+    V3 v0 = v3(tr.v[0], tr.v[1], tr.v[2]), v1 = v3(tr.v[3], tr.v[4], tr.v[5]), v2 = v3(tr.v[6], tr.v[7], tr.v[8]);
+    V3 v0v1 = v1 - v0;
+    V3 v0v2 = v2 - v0;
+    V3 nn = cross(v0v1, v0v2);
+    DTriPre q; q.n[0] = nn.x; q.n[1] = nn.y; q.n[2] = nn.z; q.dd = -dot(nn, v0);
+    pre[i] = q;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre, uint32_t n_prims,
                                                            RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                            double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
     const uint64_t n = count ? (uint64_t)*count : n_fixed;
@@ -544,10 +557,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restri
         HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
         double closest = tmax0;
         ++c_rays;
-        for (uint32_t k = 0; k < n_prims; ++k) {
-            ++c_prim;
-            DPrim P = prims[k];
-            if (hit_prim(P, (int32_t)k, o, d, tmin0, closest, rec)) closest = rec.t;
+        if (pre) {
+            for (uint32_t k = 0; k < n_prims; ++k) {
+                ++c_prim;
+                if (hit_triangle_pre(prims, pre, k, o, d, tmin0, closest, rec)) closest = rec.t;
+            }
+        } else {
+            for (uint32_t k = 0; k < n_prims; ++k) {
+                ++c_prim;
+                DPrim P = prims[k];
+                if (hit_prim(P, (int32_t)k, o, d, tmin0, closest, rec)) closest = rec.t;
+            }
         }
         store_hit(out, q, rec.prim >= 0, rec, prims);
     }
@@ -587,7 +607,7 @@ RT_DEV uint64_t grid_cell_from_point(V3 p, const DGrid& g) {            // grid.
 // extend_grid: HittableList::hit, grid arm (hittable_list.rs:94-100) = Grid::hit (grid.rs:139-147):
 // get_box_enter (:119-129) then the tail-recursive traverse (:151-183) as a loop.
 template <bool DRAW>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* __restrict__ prims,
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
     const uint64_t n = count ? (uint64_t)*count : n_fixed;
@@ -645,11 +665,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
             bool any = false;
             double closest = tmax0;
             uint64_t lo = g.cell_offset[cell], hi = g.cell_offset[cell + 1];
-            for (uint64_t k = lo; k < hi; ++k) {
-                ++c_prim;
-                uint32_t pi = g.prim_list[k];
-                DPrim P = prims[pi];
-                if (hit_prim(P, (int32_t)pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+            if (pre) {
+                for (uint64_t k = lo; k < hi; ++k) {
+                    ++c_prim;
+                    uint32_t pi = g.prim_list[k];
+                    if (hit_triangle_pre(prims, pre, pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                }
+            } else {
+                for (uint64_t k = lo; k < hi; ++k) {
+                    ++c_prim;
+                    uint32_t pi = g.prim_list[k];
+                    DPrim P = prims[pi];
+                    if (hit_prim(P, (int32_t)pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                }
             }
             if (any) {
                 rec = copy;
@@ -673,8 +701,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
         stat_add(stats, ST_GRIDBOX, c_gbox); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
-template __global__ void k_extend_grid<false>(DGrid, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
-template __global__ void k_extend_grid<true>(DGrid, const DPrim*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
+template __global__ void k_extend_grid<false>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
+template __global__ void k_extend_grid<true>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
 
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 6      // 80 VGPRs: three 512-thread blocks per CU instead of two (shade 59 -> 56.5 ms; 8 spills and is slower)
