@@ -94,6 +94,13 @@ def main():
     from raytracer_amd.dist import reduce_framebuffer, spp_range
     s_begin, s_count = spp_range(rank, world, a.spp_per_gpu * world)
 
+    # set-up that is not a step: the render workspace (one hipMalloc set of ~200 GB at the default size) and the communicator's
+    # first collective, so that a run with --warmup 0 times steps and nothing else
+    cam.reserve(w, s_count)
+    if world > 1:
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+
     def step():
         _, st = cam.render(w, seed=1, s_begin=s_begin, s_count=s_count, d_out=fb.data_ptr(), stream=stream)
         reduce_framebuffer(fb, dst=0)                        # RCCL over xGMI: the one exchange step of the path

@@ -207,18 +207,10 @@ void fill_stats(rt_stats* s, const unsigned long long* h) {
     s->ray_segments = h[ST_SEGMENTS];
 }
 
-int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
-                uint64_t seed, double* d_fb, hipStream_t st, rt_stats* stats) {
-    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
-    if (!sc || !cam || !d_fb) return fail(RT_E_ARG, "null argument");
-    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
-    if (WH == 0 || WH > 0x7fffffffull) return fail(RT_E_LIMIT, "image of %llu pixels is outside (0, 2^31)", (unsigned long long)WH);
-    if (algorithm == RT_ALGO_BVH && !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
-    if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
-    if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
-
-    // Batch = as many samples per pixel in flight as HBM comfortably holds (196 B of queue state per path): long paths
-    // leave a tail of small, latency-bound launches per batch, so fewer, larger batches are faster (288 GB per GPU).
+// Batch = as many samples per pixel in flight as HBM comfortably holds (196 B of queue state per path): long paths
+// leave a tail of small, latency-bound launches per batch, so fewer, larger batches are faster (288 GB per GPU).
+// Sizes (and, when needed, allocates) the scene's workspace for renders of s_count samples of a WH-pixel image; *k_out = samples per batch.
+int size_workspace(rt_scene* sc, uint64_t WH, uint32_t s_count, uint32_t max_depth, uint32_t* k_out) {
     uint64_t batch_paths = g_batch_paths;
     if (batch_paths == 0) {
         size_t free_b = 0, total_b = 0;
@@ -240,6 +232,23 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         rc = ensure_workspace(sc, WH * k, max_depth + 2);
     }
     if (rc) return rc;
+    *k_out = k;
+    return RT_OK;
+}
+
+int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                uint64_t seed, double* d_fb, hipStream_t st, rt_stats* stats) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!sc || !cam || !d_fb) return fail(RT_E_ARG, "null argument");
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    if (WH == 0 || WH > 0x7fffffffull) return fail(RT_E_LIMIT, "image of %llu pixels is outside (0, 2^31)", (unsigned long long)WH);
+    if (algorithm == RT_ALGO_BVH && !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
+    if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
+    if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
+
+    uint32_t k = 0;
+    { const int rcw = size_workspace(sc, WH, s_count, max_depth, &k); if (rcw) return rcw; }
+    int rc = RT_OK;
     Workspace& w = sc->ws;
 
     DCamera dc; dc.W = cam->image_width; dc.H = cam->image_height;
@@ -673,6 +682,15 @@ int rt_generate(const rt_camera* cam, uint64_t seed, uint32_t sample, const uint
     HIPCHECK(hipMemcpy(dir, d_d, n * 24, hipMemcpyDeviceToHost));
     (void)hipFree(d_i); (void)hipFree(d_j); (void)hipFree(d_o); (void)hipFree(d_d);
     return RT_OK;
+}
+
+int rt_scene_reserve(rt_scene* sc, uint32_t image_width, uint32_t image_height, uint32_t s_count, uint32_t max_depth) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!sc) return fail(RT_E_ARG, "null argument");
+    const uint64_t WH = (uint64_t)image_width * image_height;
+    if (WH == 0 || WH > 0x7fffffffull) return fail(RT_E_LIMIT, "image of %llu pixels is outside (0, 2^31)", (unsigned long long)WH);
+    uint32_t k = 0;
+    return size_workspace(sc, WH, s_count, max_depth, &k);
 }
 
 int rt_render_device(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,

@@ -287,6 +287,13 @@ class Camera:
                                          out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
 
+    def reserve(self, world, s_count=None):
+        """rt_scene_reserve: allocate the render workspace for this camera's image now instead of inside the first render."""
+        if world._dev is None:
+            raise RtError("world.upload() first")
+        _hip_check(F.hip_lib().rt_scene_reserve(world._dev, self.image_width, self.image_height,
+                                                int(self.samples_per_pixel if s_count is None else s_count), self.max_depth))
+
     def resolve(self, summed, spp_total=None):
         """camera.rs:75 + color.rs:6-30: scale by 1/spp, gamma, clamp, quantise → uint8[H,W,3]."""
         summed = np.ascontiguousarray(summed, dtype=np.float64)

@@ -186,6 +186,23 @@ def test_queue_order_does_not_change_the_image(gpu, monkeypatch, scene, width, s
     w.close()
 
 
+def test_reserve_allocates_ahead_and_changes_nothing(gpu):
+    """rt_scene_reserve sizes the workspace a render would; the image is the one an unreserved scene renders."""
+    from raytracer_amd import RtError
+    a = load_world("simple_hollow_glass"); a.algorithm = "bvh"; a.init(); a.upload()
+    b = load_world("simple_hollow_glass"); b.algorithm = "bvh"; b.init(); b.upload()
+    cam = Camera(a.filename, image_width=80, samples_per_pixel=5)
+    cam.reserve(b); cam.reserve(b, 2)                                  # twice, and for fewer samples: no-ops after the first
+    ia, sa = cam.render(a, seed=3); ib, sb = cam.render(b, seed=3)
+    assert np.array_equal(ia, ib) and sa["scatter_rays"] == sb["scatter_rays"]
+    big = Camera(a.filename, image_width=200, samples_per_pixel=9)       # a larger render afterwards still resizes by itself
+    assert np.array_equal(big.render(a, seed=3)[0], big.render(b, seed=3)[0])
+    c = load_world("simple_hollow_glass")
+    with pytest.raises(RtError):
+        cam.reserve(c)                                                 # not uploaded
+    a.close(); b.close()
+
+
 def test_full_size_properties_weekend_final(gpu):
     """configs[1] at full size (1920x1080; 2 of the 256 spp): size-independent properties only —
     exact primary count, finite non-negative radiance bounded by the sky colour, and the image of samples
