@@ -627,12 +627,16 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
     if (rc) return rc;
     Workspace& w = sc->ws;
     hipStream_t st = g_stream;
-    double *d_o = nullptr, *d_d = nullptr, *d_t = nullptr; uint8_t* d_h = nullptr;
+    struct Staging {                                         // freed on every exit path
+        double *o = nullptr, *d = nullptr, *t = nullptr; uint8_t* h = nullptr;
+        ~Staging() { if (o) (void)hipFree(o); if (d) (void)hipFree(d); if (t) (void)hipFree(t); if (h) (void)hipFree(h); }
+    } sg;
     const uint64_t cmax = n < chunk ? (n ? n : 1) : chunk;
-    HIPCHECK(hipMalloc(&d_o, cmax * 3 * sizeof(double)));
-    HIPCHECK(hipMalloc(&d_d, cmax * 3 * sizeof(double)));
-    HIPCHECK(hipMalloc(&d_t, cmax * sizeof(double)));
-    HIPCHECK(hipMalloc(&d_h, cmax));
+    HIPCHECK(hipMalloc(&sg.o, cmax * 3 * sizeof(double)));
+    HIPCHECK(hipMalloc(&sg.d, cmax * 3 * sizeof(double)));
+    HIPCHECK(hipMalloc(&sg.t, cmax * sizeof(double)));
+    HIPCHECK(hipMalloc(&sg.h, cmax));
+    double *d_o = sg.o, *d_d = sg.d, *d_t = sg.t; uint8_t* d_h = sg.h;
     HIPCHECK(hipMemsetAsync(w.stats, 0, ST_N * sizeof(unsigned long long), st));
     int ret = RT_OK;
     for (uint64_t off = 0; off < n && ret == RT_OK; off += chunk) {
@@ -657,7 +661,6 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
         if (e != hipSuccess) ret = fail(RT_E_HIP, "stats readback failed: %s", hipGetErrorString(e));
         else if (stats) { memset(stats, 0, sizeof *stats); fill_stats(stats, w.h_stats); }
     }
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_h);
     return ret;
 }
 
@@ -671,16 +674,19 @@ int rt_generate(const rt_camera* cam, uint64_t seed, uint32_t sample, const uint
     DCamera dc; dc.W = cam->image_width; dc.H = cam->image_height;
     dc.center = tov(cam->center); dc.pixel00 = tov(cam->pixel00); dc.du = tov(cam->du); dc.dv = tov(cam->dv);
     dc.ddu = tov(cam->ddu); dc.ddv = tov(cam->ddv); dc.defocus_angle = cam->defocus_angle;
-    uint32_t *d_i = nullptr, *d_j = nullptr; double *d_o = nullptr, *d_d = nullptr;
-    HIPCHECK(hipMalloc(&d_i, n * 4)); HIPCHECK(hipMalloc(&d_j, n * 4));
-    HIPCHECK(hipMalloc(&d_o, n * 24)); HIPCHECK(hipMalloc(&d_d, n * 24));
+    struct Staging {                                         // freed on every exit path
+        uint32_t *i = nullptr, *j = nullptr; double *o = nullptr, *d = nullptr;
+        ~Staging() { if (i) (void)hipFree(i); if (j) (void)hipFree(j); if (o) (void)hipFree(o); if (d) (void)hipFree(d); }
+    } sg;
+    HIPCHECK(hipMalloc(&sg.i, n * 4)); HIPCHECK(hipMalloc(&sg.j, n * 4));
+    HIPCHECK(hipMalloc(&sg.o, n * 24)); HIPCHECK(hipMalloc(&sg.d, n * 24));
+    uint32_t *d_i = sg.i, *d_j = sg.j; double *d_o = sg.o, *d_d = sg.d;
     HIPCHECK(hipMemcpy(d_i, pix_i, n * 4, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_j, pix_j, n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_generate_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, dc, sample, seed, d_i, d_j, n, d_o, d_d);
     HIPCHECK(hipStreamSynchronize(g_stream));
     HIPCHECK(hipMemcpy(orig, d_o, n * 24, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(dir, d_d, n * 24, hipMemcpyDeviceToHost));
-    (void)hipFree(d_i); (void)hipFree(d_j); (void)hipFree(d_o); (void)hipFree(d_d);
     return RT_OK;
 }
 
