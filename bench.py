@@ -12,11 +12,26 @@ One step = one pass of the hot path over the rank's batch: generate -> (extend, 
 128 spp of the 3840x2160 frame, then (N > 1) one RCCL reduce of the f64 framebuffers to rank 0.
 Timed region starts with the scene, BVH and queues resident in HBM.
 Metric: Mrays/s = (primary_rays + scatter_rays) / seconds / 1e6, whole job (src/camera.rs:70,171).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N ranks itself (torch.distributed.run,
+one per GPU) before it touches torch or the GPU, and relays rank 0's JSON line.  Under torchrun the ranks check that
+WORLD_SIZE equals --gpus.
+
+Roofline (N = 1): after the timed steps the workspace is released and the same workload is run once more under
+`rocprofv3 --pmc` in child processes (one pass per counter group), so the VALU and fabric-traffic figures on the line come
+from counters of this run's own kernels; `--no-pmc` skips that and the line says so.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import signal
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -37,7 +52,18 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsing N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that feed the roofline")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the profiled re-run: one step, counters only
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """--gpus N without a launcher: start N ranks (one process per GPU) from a parent that never touches the GPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def load_scene(name):
@@ -60,8 +86,12 @@ def load_scene(name):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU, or let --gpus start them")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -133,16 +163,12 @@ def main():
     dt = float(tt.item()); total_rays = float(rays.item())
 
     if rank == 0:
-        # roofline of the dominant kernel (extend_bvh), per launch, from this rank's counters and HIP-event times
         seg, nbox, nprim = agg["ray_segments"], agg["box_tests"], agg["prim_tests"]
         launches = max(agg["extend_launches"], 1)
-        alg_bytes = 60.0 * seg + 64.0 * nbox + 72.0 * nprim     # (48 in + 12 out) + 64/box + 72/triangle
         ext_s = agg["extend_ms"] / 1e3
-        achieved = alg_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
         pair_b, prim_b = w.bvh_layout()                         # what the kernel's layout for this scene really reads
-        layout_bytes = 60.0 * seg + 0.5 * pair_b * nbox + prim_b * nprim
-        pmc = pmc_figures()
-        lane_acc = ((pair_b / 16.0) * 0.5 * nbox + (prim_b / 16.0) * nprim + 6.0 * seg) / ext_s / (256 * 2.4e9) if ext_s > 0 else 0.0
+        counts = {"segments": seg, "box_tests": nbox, "prim_tests": nprim, "launches": launches, "extend_s": ext_s,
+                  "pair_bytes": pair_b, "prim_bytes": prim_b}
         out = {
             "metric": "Mrays/s (whole node) dragon PLY BVH; PSNR vs CPU render checked in tests",
             "value": total_rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -151,25 +177,21 @@ def main():
             "config": {"workload": f"{label}; --algorithm bvh (SAH position); {W}x{H}; {a.spp_per_gpu} spp per GPU "
                                    f"({a.spp_per_gpu * world} spp total, spp-split); max_depth {a.max_depth}; camera preset dragon/0",
                        "primitives": len(w), "bvh_nodes": w.bvh.n_nodes, "bvh_depth": w.bvh.depth,
-                       "parallelism": f"spp-split x{world}, replicated scene, one RCCL reduce of the f64 framebuffer per step" if world > 1 else "single GPU",
+                       "parallelism": f"spp-split x{world}, replicated scene, one RCCL reduce of the f64 framebuffer per step ({world} ranks)" if world > 1 else "single GPU",
                        "init_seconds_excluded": round(init_s, 2)},
             "rays_per_step": total_rays / a.steps,
             "kernel_ms_per_step": {k: agg[k] / a.steps for k in ("generate_ms", "extend_ms", "shade_ms", "resolve_ms")},
-            "roofline": {"kernel": "k_extend_bvh2", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": measured_traffic(seg / launches),
-                         "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": agg["extend_ms"] / launches,
-                         "launches": launches, "bytes_per_segment": alg_bytes / max(seg, 1),
-                         "box_tests_per_segment": nbox / max(seg, 1), "prim_tests_per_segment": nprim / max(seg, 1),
-                         # the kernel's own layout (f32-lattice pairs / triangles when the scene allows): bytes it requests
-                         "layout": {"pair_bytes": pair_b, "prim_bytes": prim_b, "requested_GBps": layout_bytes / ext_s / 1e9 if ext_s > 0 else 0.0},
-                         # what actually bounds it: divergent 16-B lane accesses at ~1 per clock per CU in the vector L1,
-                         # and VALU issue; figures from the committed PMC passes of the same kernel, not from this run
-                         "lane_accesses_per_clk_per_cu": lane_acc,
-                         # what actually bounds this kernel: divergent <=16-B lane accesses per clock per CU against the
-                         # 1.1 measured in a pure gather (tools/mb/mb_gather.hip, profiles/round1_mb_gather.txt)
-                         "l1_lane_access_bound": {"achieved": lane_acc, "peak": 1.1, "unit": "lane accesses/clk/CU", "frac": lane_acc / 1.1},
-                         "pmc": pmc},
         }
+        if a.pmc_child:                                         # the profiled re-run only reports what the parent normalises by
+            out["pmc_child"] = counts
+            print(json.dumps(out), flush=True)
+            return
+        pmc = None
+        if world == 1 and not a.no_pmc:
+            # free this process's HBM (the workspace alone is ~200 GB) before the profiled children allocate theirs
+            w.close(); del fb; torch.cuda.empty_cache()
+            pmc = pmc_passes(a)
+        out["roofline"] = roofline(counts, pmc)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, cam_name, a)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
@@ -179,22 +201,133 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(segments_per_launch):
-    """HBM-side bytes per extend launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE per ray segment,
-    profiles/round1_traffic.json) scaled to this run's segments per launch; None when the file is absent."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
-        return (t["fetch_bytes_per_segment_corrected_x2"] + t["write_bytes_per_segment"]) * segments_per_launch
-    except Exception:
-        return None
+# ---- roofline of the dominant kernel (k_extend_bvh2) ----------------------------------------------------------------
+# Hardware figures (MI355X_MICROARCH.md): HBM3E 8 TB/s; vector f64 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x
+# 2.4 GHz, i.e. 3.93e13 VALU lane-operations per second at full rate (every f64 and integer instruction of this kernel
+# issues at that rate: tools/mb/mb_valu.hip; only rcp/rsq are slower and the traversal loop has none).
+VALU_PEAK_LANE_OPS = 256 * 64 * 2.4e9
+HBM_PEAK_GBPS = 8000.0
+PMC_PASSES = {
+    "sq": "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE",
+    "fetch": "FETCH_SIZE",
+    "write": "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
+}
 
 
-def pmc_figures():
+def fetch_calibration():
+    """FETCH_SIZE bytes reported per byte really fetched, for this kernel's access shape (per-lane 16-B loads of 64-B records
+    at unrelated addresses), measured by tools/mb/mb_fetch.hip under the same counter: profiles/round2_fetch_calibration.json.
+    The guide's x2 rule is for wide streaming reads only."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
-        return {k: t[k] for k in ("valu_busy_per_simd", "valu_lane_utilisation", "l2_hit_rate", "wave_wait_fraction", "source") if k in t}
+        c = json.load(open(os.path.join(ROOT, "profiles", "round2_fetch_calibration.json")))
+        return float(c["bytes_fetched_per_byte_reported"]), c.get("source", "profiles/round2_fetch_calibration.json")
     except Exception:
-        return None
+        return 1.0, "uncalibrated (FETCH_SIZE taken as reported)"
+
+
+def pmc_passes(a):
+    """One `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` per counter group: the same workload, one step.
+    Returns {"counters": {name: sum over the extend dispatches}, "child": counts of the profiled step, ...} or a dict with
+    "error".  Each pass is a fresh process (the profiler's library initialises the GPU before the program starts)."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="rt_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    keep = os.path.join(ROOT, "gpurun_out", "bench_pmc")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc",
+             "--width", str(a.width), "--spp-per-gpu", str(a.spp_per_gpu), "--max-depth", str(a.max_depth), "--scene", a.scene]
+    res = {"counters": {}, "dispatches": 0, "child": None, "seconds": {}, "kernel_ns": 0.0,
+           "source": "rocprofv3 --pmc passes of this run's own workload (one step per pass, separate child processes)"}
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    for name, ctrs in PMC_PASSES.items():
+        d = os.path.join(tmp, name)
+        cmd = [prof, "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", name, "--"] + child
+        t0 = time.time()
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                log, _ = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL); p.wait()
+                res["error"] = f"pass {name}: timed out"; break
+        except OSError as e:
+            res["error"] = f"pass {name}: {e}"; break
+        res["seconds"][name] = round(time.time() - t0, 1)
+        lines = [l for l in log.splitlines() if l.startswith('{"metric"')]
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not lines or not f:
+            res["error"] = f"pass {name}: rc {p.returncode}; " + log[-300:].replace("\n", " | "); break
+        if res["child"] is None:
+            res["child"] = json.loads(lines[-1])["pmc_child"]
+        seen = set()
+        for r in csv.DictReader(open(f[0])):
+            if "k_extend_bvh2" not in r["Kernel_Name"]:
+                continue
+            res["counters"][r["Counter_Name"]] = res["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            if name == "sq" and r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"]); res["kernel_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        if name == "sq":
+            res["dispatches"] = len(seen)
+        try:                                                   # keep the raw csv where a gpurun call merges it back
+            os.makedirs(keep, exist_ok=True); shutil.copy(f[0], os.path.join(keep, f"{name}_counter_collection.csv"))
+        except OSError:
+            pass
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def roofline(c, pmc):
+    seg, nbox, nprim, launches, ext_s = c["segments"], c["box_tests"], c["prim_tests"], c["launches"], c["extend_s"]
+    pair_b, prim_b = c["pair_bytes"], c["prim_bytes"]
+    alg_bytes = 60.0 * seg + 64.0 * nbox + 72.0 * nprim          # SURVEY 8(d): (48 in + 12 out) + 64 per box test + 72 per triangle test
+    layout_bytes = 60.0 * seg + 0.5 * pair_b * nbox + prim_b * nprim
+    lane_acc = ((pair_b / 16.0) * 0.5 * nbox + (prim_b / 16.0) * nprim + 6.0 * seg) / ext_s / (256 * 2.4e9) if ext_s > 0 else 0.0
+    r = {"kernel": "k_extend_bvh2", "avg_launch_ms": ext_s * 1e3 / launches, "launches": launches,
+         # the contract's byte model, as plain fields: it prices every box test at 64 B from HBM, while the tree sits in the
+         # Infinity Cache / L2 and the compact layout requests half of it, so this rate can exceed the HBM peak and is no bound
+         "algorithmic_bytes_per_launch": alg_bytes / launches, "algorithmic_GBps": alg_bytes / ext_s / 1e9 if ext_s > 0 else 0.0,
+         "bytes_per_segment": alg_bytes / max(seg, 1), "box_tests_per_segment": nbox / max(seg, 1), "prim_tests_per_segment": nprim / max(seg, 1),
+         "layout": {"pair_bytes": pair_b, "prim_bytes": prim_b, "requested_GBps": layout_bytes / ext_s / 1e9 if ext_s > 0 else 0.0},
+         # secondary, against a self-measured peak: divergent <=16-B lane accesses per clock per CU vs the 1.1 of a pure gather
+         # (tools/mb/mb_gather.hip, profiles/round1_mb_gather.txt)
+         "l1_lane_access_bound": {"achieved": lane_acc, "peak": 1.1, "unit": "lane accesses/clk/CU", "frac": lane_acc / 1.1}}
+    k = (pmc or {}).get("counters") or {}
+    ch = (pmc or {}).get("child") or {}
+    need = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")
+    if pmc and "error" not in pmc and all(k.get(n) for n in need) and ch.get("segments"):
+        # counters are sums over the extend dispatches of ONE profiled step; the work per segment is deterministic (same seed,
+        # same paths), so they are scaled by segments to the timed steps and divided by the un-profiled HIP-event time
+        scale = seg / ch["segments"]
+        lane_util = k["SQ_THREAD_CYCLES_VALU"] / (k["SQ_ACTIVE_INST_VALU"] * 64.0)
+        useful = k["SQ_INSTS_VALU"] * 64.0 * lane_util * scale     # lane-operations that did work
+        issued = k["SQ_INSTS_VALU"] * 64.0 * scale                 # lane slots the issued instructions occupied
+        achieved = useful / ext_s
+        r.update({"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s (f64-rate VALU)",
+                  "frac": achieved / VALU_PEAK_LANE_OPS,
+                  "valu": {"lane_utilisation": lane_util, "issue_frac": issued / ext_s / VALU_PEAK_LANE_OPS,
+                           "valu_wave_insts_per_segment": k["SQ_INSTS_VALU"] / ch["segments"],
+                           "wave_wait_fraction": k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
+                           "clock_GHz_profiled": (k["GRBM_GUI_ACTIVE"] / 8.0 / pmc["kernel_ns"]) if k.get("GRBM_GUI_ACTIVE") and pmc.get("kernel_ns") else None}})
+        if k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
+            cal, cal_src = fetch_calibration()
+            fetch_b = k["FETCH_SIZE"] * 1e3 * cal * scale; write_b = k["WRITE_SIZE"] * 1e3 * scale
+            r["traffic"] = (fetch_b + write_b) / launches
+            r["hbm"] = {"bound": "hbm", "achieved": (fetch_b + write_b) / ext_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": (fetch_b + write_b) / ext_s / 1e9 / HBM_PEAK_GBPS,
+                        "fetch_bytes_per_segment": fetch_b / seg, "write_bytes_per_segment": write_b / seg,
+                        "fetch_size_calibration": cal, "calibration_source": cal_src,
+                        "l2_hit_rate": k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if k.get("TCC_HIT_sum") and k.get("TCC_MISS_sum") is not None else None,
+                        "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted as fetches), so an upper bound of the HBM traffic"}
+        else:
+            r["traffic"] = None
+        r["pmc"] = {"source": pmc["source"], "dispatches_profiled": pmc["dispatches"], "pass_seconds": pmc["seconds"],
+                    "counters": {n: v for n, v in sorted(k.items())}, "segments_profiled": ch["segments"]}
+    else:
+        # no counters from this run: the fraction that needs none (lane accesses against the measured gather rate) is the
+        # headline, and the line says why
+        r.update({"bound": "l1_lane_access", "achieved": lane_acc, "peak": 1.1, "unit": "lane accesses/clk/CU", "frac": lane_acc / 1.1,
+                  "traffic": None, "pmc": {"source": "none", "reason": (pmc or {}).get("error", "PMC passes not run (--no-pmc or N > 1)")}})
+    return r
 
 
 def cpu_baseline(w, cam_name, a):

@@ -140,8 +140,10 @@ int rt_render(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint
               uint64_t seed, double* out_sum, rt_stats* stats);
 
 /* Same, but the framebuffer stays in HBM: d_out_sum is a device buffer of W*H*3 doubles that is
- * overwritten, and the call is ordered after prior work on `stream` (a hipStream_t, may be NULL) and
- * complete on return.  This is what an spp-split multi-GPU host reduces with RCCL. */
+ * overwritten.  The call waits (on the host) for prior work on `stream` and is complete on return.  `stream` is a
+ * hipStream_t: the kernels run on it; NULL means the legacy default stream, in which case the kernels run on the library's
+ * own non-blocking stream after the default stream has drained.  This is what an spp-split multi-GPU host reduces with RCCL.
+ * max_depth == 0 gives a black frame and no counters but primary_rays (camera.rs:155-157); max_depth > 2^20 is RT_E_LIMIT. */
 int rt_render_device(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
                      uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats);
 

@@ -32,7 +32,11 @@ int fail(int code, const char* fmt, ...) {
 bool g_inited = false;
 int g_device = -1;
 bool g_profiling = false;
-hipStream_t g_stream = nullptr;
+hipStream_t g_stream = nullptr;       // the current device's stream (g_dev[g_device].stream)
+// what rt_init keeps per device: the library's stream and two events for the pipelined queue-length read-back
+#define RT_MAX_DEVICES 64
+struct DevState { hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+DevState g_dev[RT_MAX_DEVICES];
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
 uint32_t g_stream_blocks = 4096;
 // k_accumulate: each lane streams one pixel's run of samples, so a wave keeps 64 cache lines live; four waves per CU keep
@@ -68,9 +72,11 @@ struct Workspace {
     double* rad = nullptr;
     uint32_t* counts = nullptr;      // queue lengths per bounce, then (at +depth_cap) the extend kernels' fetch counters
     unsigned long long* stats = nullptr;
-    uint32_t* h_count = nullptr; // pinned
+    uint32_t* h_count = nullptr; // pinned, 16 words: ring of the last queue lengths read back
     unsigned long long* h_stats = nullptr;
+    bool is_static = false;      // a view of memory the workspace does not own: nothing to free, no pinned host words
     void release() {
+        if (is_static) return;
         for (int i = 0; i < 2; ++i) { if (qbuf[i]) (void)hipFree(qbuf[i]); if (qid[i]) (void)hipFree(qid[i]); qbuf[i] = nullptr; qid[i] = nullptr; }
         if (hit_prim) (void)hipFree(hit_prim); if (hit_tp) (void)hipFree(hit_tp); if (hit_tn) (void)hipFree(hit_tn); if (rad) (void)hipFree(rad);
         if (counts) (void)hipFree(counts); if (stats) (void)hipFree(stats);
@@ -102,6 +108,7 @@ struct rt_scene {
     bool have_bvh = false; uint32_t n_nodes = 0, bvh_depth = 0;
     bool bvh_empty_leaf = false;       // a leaf without primitives (only the root of an empty scene): plain kernel only
     DNode* d_nodes = nullptr; DPrim* d_prims_bvh = nullptr; StackEntry* d_stack = nullptr;
+    uint32_t stack_blocks = 0;         // extend blocks d_stack was sized for (RT_EXTEND_BLOCKS may change between rt_init calls)
     DPair32* d_pairs32 = nullptr; DPrim32* d_prims32 = nullptr; double lattice_scale = 0.0;   // compact forms; scale 0 = not available
     DPair64* d_pairs64 = nullptr; DSphere* d_spheres = nullptr;                               // generic pairs; spheres only for all-sphere scenes
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
@@ -151,24 +158,27 @@ int ensure_workspace(rt_scene* sc, uint64_t cap, uint32_t depth_cap) {
 }
 
 int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* count, uint64_t n_fixed, double tmin, double tmax,
-                  const ExtendOut& out, uint32_t* fetch_ctr, hipStream_t st, uint64_t n_hint = 0) {
-    // n_hint = queue length when the host knows it (0: unknown): a short queue gets a grid of one lane per ray instead of 4096
-    // waves that each pay an atomic on the fetch counter to learn that nothing is left (88 per microsecond on one word)
+                  const ExtendOut& out, uint32_t* fetch_ctr, unsigned long long* d_stats, hipStream_t st, uint64_t n_hint = 0) {
+    // n_hint = an upper bound of the queue length when the host knows one (0: unknown): a short queue gets a grid of one lane
+    // per ray instead of 4096 waves that each pay an atomic on the fetch counter to learn that nothing is left (88 per
+    // microsecond on one word).  Without a hint the persistent kernel's surplus blocks leave on their own (they read *count).
     uint32_t nblk = g_extend_blocks;
+    // the BVH kernels index the continuation stack by (level, thread): never launch more blocks than it was sized for
+    if (algorithm == RT_ALGO_BVH && sc->stack_blocks && nblk > sc->stack_blocks) nblk = sc->stack_blocks;
     if (n_hint) { const uint64_t want = ((n_hint + RT_BLOCK - 1) / RT_BLOCK + 7) & ~7ull; if (want < nblk) nblk = (uint32_t)want; }
     dim3 grid(nblk), block(RT_BLOCK);
     switch (algorithm) {
     case RT_ALGO_BVH:
         if (!sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called (reference: \"Please run HittableList.init() first\")");
         if (sc->draw_boxes)            // debug overlay: the simple one-ray-per-thread kernel carries the edge flag
-            hipLaunchKernelGGL(k_extend_bvh<true>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+            hipLaunchKernelGGL(k_extend_bvh<true>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, d_stats);
         else if (g_extend_variant == 1 || sc->bvh_empty_leaf)
-            hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, sc->ws.stats);
+            hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, d_stats);
         else {
             BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs64 = sc->d_pairs64; v.spheres = sc->d_spheres;
             v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
             const bool c32 = g_compact && sc->lattice_scale > 0.0, sph = g_compact && sc->d_spheres != nullptr;
-#define RT_LAUNCH_BVH2(N, P, T) hipLaunchKernelGGL((k_extend_bvh2<N, P, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, sc->ws.stats, g_dbg)
+#define RT_LAUNCH_BVH2(N, P, T) hipLaunchKernelGGL((k_extend_bvh2<N, P, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, d_stats, g_dbg)
             if (c32)      { if (out.trace) RT_LAUNCH_BVH2(1, 1, true); else RT_LAUNCH_BVH2(1, 1, false); }
             else if (sph) { if (out.trace) RT_LAUNCH_BVH2(0, 2, true); else RT_LAUNCH_BVH2(0, 2, false); }
             else          { if (out.trace) RT_LAUNCH_BVH2(0, 0, true); else RT_LAUNCH_BVH2(0, 0, false); }
@@ -176,7 +186,7 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         }
         break;
     case RT_ALGO_NAIVE:
-        hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->d_tri_pre, sc->n_prims, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+        hipLaunchKernelGGL(k_extend_naive, grid, block, 0, st, sc->d_prims, sc->d_tri_pre, sc->n_prims, in, count, n_fixed, tmin, tmax, out, d_stats);
         break;
     case RT_ALGO_GRID: {
         if (!sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called (reference: \"Please run Grid::new() first\")");
@@ -184,9 +194,9 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         // with nearly empty cells (size 1) the second array only costs cache (+5 %)
         const DTriPre* gpre = (sc->grid_list_len * 10ull >= sc->grid.n_cells) ? sc->d_tri_pre : nullptr;
         if (sc->draw_boxes)
-            hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+            hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, d_stats);
         else
-            hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, sc->ws.stats);
+            hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, d_stats);
         break;
     }
     default:
@@ -236,20 +246,20 @@ int size_workspace(rt_scene* sc, uint64_t WH, uint32_t s_count, uint32_t max_dep
     return RT_OK;
 }
 
-int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+// The bounce loop.  `w` is the workspace the call runs in (the scene's own, sized from free HBM by size_workspace);
+// k = samples per pixel per batch, already fitted to w.cap.
+// Queue lengths: every kernel strides over *count in device memory, so the host needs them only to stop early and to give
+// short queues a small grid.  The read-back is pipelined: bounce b+1 is launched before the host looks at the length bounce b
+// produced (an empty queue costs two launches that find nothing to do), so the GPU never waits for the host between bounces;
+// a queue never grows (a path scatters into at most one ray), so the last length read is an upper bound for the launch shape.
+// Without pinned host words nothing is read back and all max_depth bounces are launched.
+int render_impl(rt_scene* sc, Workspace& w, uint32_t k, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
                 uint64_t seed, double* d_fb, hipStream_t st, rt_stats* stats) {
-    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
-    if (!sc || !cam || !d_fb) return fail(RT_E_ARG, "null argument");
     const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
-    if (WH == 0 || WH > 0x7fffffffull) return fail(RT_E_LIMIT, "image of %llu pixels is outside (0, 2^31)", (unsigned long long)WH);
-    if (algorithm == RT_ALGO_BVH && !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
-    if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
-    if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
-
-    uint32_t k = 0;
-    { const int rcw = size_workspace(sc, WH, s_count, max_depth, &k); if (rcw) return rcw; }
     int rc = RT_OK;
-    Workspace& w = sc->ws;
+    const bool profiling = g_profiling && !w.is_static;
+    const bool readback = w.h_count != nullptr;
+    DevState& dev = g_dev[g_device];
 
     DCamera dc; dc.W = cam->image_width; dc.H = cam->image_height;
     dc.center = tov(cam->center); dc.pixel00 = tov(cam->pixel00); dc.du = tov(cam->du); dc.dv = tov(cam->dv);
@@ -261,8 +271,8 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
     std::vector<TimedSpan> spans;
     g_events.reset();
     double ms[4] = {0, 0, 0, 0}; uint64_t extend_launches = 0;
-    auto begin_span = [&](int kind) { if (g_profiling) { TimedSpan s; s.a = g_events.get(); s.b = g_events.get(); s.kind = kind; (void)hipEventRecord(s.a, st); spans.push_back(s); } };
-    auto end_span = [&]() { if (g_profiling) (void)hipEventRecord(spans.back().b, st); };
+    auto begin_span = [&](int kind) { if (profiling) { TimedSpan s; s.a = g_events.get(); s.b = g_events.get(); s.kind = kind; (void)hipEventRecord(s.a, st); spans.push_back(s); } };
+    auto end_span = [&]() { if (profiling) (void)hipEventRecord(spans.back().b, st); };
     auto drain_spans = [&]() {
         for (const TimedSpan& s : spans) { float f = 0; if (hipEventElapsedTime(&f, s.a, s.b) == hipSuccess) ms[s.kind] += f; }
         spans.clear(); g_events.reset();
@@ -274,8 +284,9 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
     if (algorithm == RT_ALGO_BVH && !sc->draw_boxes) { rb.enabled = 1; for (int c = 0; c < 3; ++c) { rb.mn[c] = sc->root_mn[c]; rb.mx[c] = sc->root_mx[c]; } }
     const DPrim* sprims = shade_prims(sc, algorithm);
     bool first = true;
-    if (s_count == 0) HIPCHECK(hipMemsetAsync(d_fb, 0, WH * 3 * sizeof(double), st));
-    for (uint32_t s0 = 0; s0 < s_count; s0 += k) {
+    // camera.rs:155-157: with max_depth == 0 ray_color returns black before world.hit is called: no queue, no counters
+    if (s_count == 0 || max_depth == 0) HIPCHECK(hipMemsetAsync(d_fb, 0, WH * 3 * sizeof(double), st));
+    for (uint32_t s0 = 0; max_depth != 0 && s0 < s_count; s0 += k) {
         const uint32_t kb = (s_count - s0 < k) ? (s_count - s0) : k;
         HIPCHECK(hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st));
         begin_span(K_GENERATE);
@@ -284,47 +295,85 @@ int render_impl(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_be
         if (g_lg_samples > 6) while (lg_s > 0 && (((kb + (1u << lg_s) - 1u) >> lg_s) << lg_s) - kb > kb / 8u) --lg_s;
         hipLaunchKernelGGL(k_generate, sgrid, block, 0, st, dc, rb, s_begin + s0, kb, lg_s, seed, w.q(0), w.counts, w.rad, w.stats);
         end_span();
-        uint64_t n_known = 0;                                             // the next queue's length, once a bounce has reported it
+        uint64_t n_known = readback ? WH * kb : 0;                       // upper bound of the current queue's length (0: none)
+        const size_t span0 = spans.size();
+        uint32_t launched = 0;
         for (uint32_t b = 0; b < max_depth; ++b) {
             ExtendOut eo; eo.prim = w.hit_prim; eo.t = nullptr; eo.tp = w.hit_tp; eo.tn = sc->mixed ? w.hit_tn : nullptr; eo.hit = nullptr; eo.trace = 0;
             begin_span(K_EXTEND);
-            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, w.counts + w.depth_cap + b, st, n_known);
+            rc = launch_extend(sc, algorithm, w.q(b & 1), w.counts + b, 0, 0.001, __builtin_huge_val(), eo, w.counts + w.depth_cap + b, w.stats, st, n_known);
             if (rc) return rc;
-            end_span(); ++extend_launches;
+            end_span();
             begin_span(K_SHADE);
             hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, sc->n_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
                                w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, kb, b, max_depth, seed, w.stats);
             end_span();
-            HIPCHECK(hipMemcpyAsync(w.h_count, w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
-            if (g_profiling && g_bounce_log) {                           // diagnostic: RT_BOUNCE_LOG=1 with profiling on
-                float fe = 0, fs = 0; const size_t ns = spans.size();
-                (void)hipEventElapsedTime(&fe, spans[ns - 2].a, spans[ns - 2].b); (void)hipEventElapsedTime(&fs, spans[ns - 1].a, spans[ns - 1].b);
-                fprintf(stderr, "bounce %2u: extend %9.3f ms, shade %8.3f ms, rays out %u\n", b, fe, fs, *w.h_count);
-            }
-            if (g_profiling) drain_spans();
-            if (*w.h_count == 0) break;
-            n_known = *w.h_count;
+            ++launched;
+            if (!readback) continue;
+            HIPCHECK(hipMemcpyAsync(w.h_count + (b & 1), w.counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipEventRecord(dev.ev[b & 1], st));
+            if (b == 0) continue;
+            HIPCHECK(hipEventSynchronize(dev.ev[(b - 1) & 1]));         // bounce b is in flight while the host looks at what bounce b-1 left
+            const uint32_t left = w.h_count[(b - 1) & 1];                // = length of the queue bounce b was launched on
+            if (left == 0) { --launched; break; }
+            n_known = left;
         }
+        extend_launches += launched;
         begin_span(K_RESOLVE);
         hipLaunchKernelGGL(k_accumulate, dim3(g_acc_blocks), dim3(g_acc_threads), 0, st, w.rad, (uint32_t)WH, kb, d_fb, first ? 1 : 0);
         end_span();
         first = false;
+        if (profiling) {
+            HIPCHECK(hipStreamSynchronize(st));
+            if (g_bounce_log)                                            // diagnostic: RT_BOUNCE_LOG=1 with profiling on
+                for (size_t i = span0, b = 0; i + 1 < spans.size() && spans[i].kind == K_EXTEND; i += 2, ++b) {
+                    float fe = 0, fs = 0;
+                    (void)hipEventElapsedTime(&fe, spans[i].a, spans[i].b); (void)hipEventElapsedTime(&fs, spans[i + 1].a, spans[i + 1].b);
+                    fprintf(stderr, "bounce %2zu: extend %9.3f ms, shade %8.3f ms\n", b, fe, fs);
+                }
+            drain_spans();
+        }
     }
-    HIPCHECK(hipMemcpyAsync(w.h_stats, w.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    unsigned long long h_stats_local[ST_N];                              // static workspace: no pinned words, plain blocking copy
+    unsigned long long* hs = w.h_stats ? w.h_stats : h_stats_local;
+    if (w.h_stats) HIPCHECK(hipMemcpyAsync(hs, w.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    if (!w.h_stats) HIPCHECK(hipMemcpy(hs, w.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHECK(hipGetLastError());
-    if (g_profiling) drain_spans();
+    if (profiling) drain_spans();
     auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         memset(stats, 0, sizeof *stats);
-        fill_stats(stats, w.h_stats);
+        fill_stats(stats, hs);
         stats->primary_rays = WH * s_count;                           /* camera.rs:70, exact */
         stats->extend_launches = extend_launches;
         stats->generate_ms = ms[K_GENERATE]; stats->extend_ms = ms[K_EXTEND]; stats->shade_ms = ms[K_SHADE]; stats->resolve_ms = ms[K_RESOLVE];
         stats->render_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     }
     return RT_OK;
+}
+
+// argument checks shared by the render entry points
+#define RT_MAX_DEPTH_LIMIT 0x100000u       // counts[] holds two words per bounce; the reference's usual depth is 50 (main.rs:76)
+int check_render_args(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t max_depth, const double* d_fb) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!sc || !cam || !d_fb) return fail(RT_E_ARG, "null argument");
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    if (WH == 0 || WH > 0x7fffffffull) return fail(RT_E_LIMIT, "image of %llu pixels is outside (0, 2^31)", (unsigned long long)WH);
+    if (algorithm < 0 || algorithm > 2) return fail(RT_E_ARG, "unknown algorithm %d", algorithm);
+    if (algorithm == RT_ALGO_BVH && !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
+    if (algorithm == RT_ALGO_GRID && !sc->have_grid) return fail(RT_E_STATE, "rt_scene_set_grid() has not been called");
+    if (max_depth > RT_MAX_DEPTH_LIMIT) return fail(RT_E_LIMIT, "max_depth %u is above the limit of %u", max_depth, RT_MAX_DEPTH_LIMIT);
+    return RT_OK;
+}
+
+int render_dynamic(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                   uint64_t seed, double* d_fb, hipStream_t st, rt_stats* stats) {
+    { const int rca = check_render_args(sc, cam, algorithm, max_depth, d_fb); if (rca) return rca; }
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    uint32_t k = 0;
+    { const int rcw = size_workspace(sc, WH, s_count, max_depth, &k); if (rcw) return rcw; }
+    return render_impl(sc, sc->ws, k, cam, algorithm, s_begin, s_count, max_depth, seed, d_fb, st, stats);
 }
 
 } // namespace
@@ -338,11 +387,15 @@ int rt_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(RT_E_HIP, "no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(RT_E_ARG, "device %d out of range [0,%d)", device, n);
+    if (device >= RT_MAX_DEVICES) return fail(RT_E_LIMIT, "device %d: this library keeps state for %d devices", device, RT_MAX_DEVICES);
     HIPCHECK(hipSetDevice(device));
-    if (!g_inited || g_device != device) {
-        HIPCHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-        g_device = device;
+    DevState& dv = g_dev[device];
+    if (!dv.stream) {                                 // first rt_init on this device; a later one finds its stream again
+        HIPCHECK(hipStreamCreateWithFlags(&dv.stream, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&dv.ev[0], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&dv.ev[1], hipEventDisableTiming));
     }
+    g_stream = dv.stream; g_device = device;
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
@@ -468,6 +521,9 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
             covered += nd.count; if (nd.count == 0) empty_leaf = true;
         } else {
             if (nd.right != nd.left + 1) return fail(RT_E_ARG, "node %u: children %u,%u are not adjacent (bvh.rs:167-168 makes them so)", i, nd.left, nd.right);
+            // bvh.rs:167-169 hands out child indices in pairs starting at 1, so a left child's index is odd; the pair tables
+            // of the persistent kernel are addressed by (left + 1) / 2 and rely on it
+            if ((nd.left & 1u) == 0u) return fail(RT_E_ARG, "node %u: left child %u has an even index (bvh.rs:167-169 numbers children 2k+1, 2k+2)", i, nd.left);
             todo.push_back({nd.right, d + 1}); todo.push_back({nd.left, d + 1});
         }
     }
@@ -492,6 +548,7 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     HIPCHECK(hipMalloc(&sc->d_nodes, dn.size() * sizeof(DNode)));
     HIPCHECK(hipMalloc(&sc->d_prims_bvh, dp.size() * sizeof(DPrim)));
     HIPCHECK(hipMalloc(&sc->d_stack, (size_t)depth * g_extend_blocks * RT_BLOCK * sizeof(StackEntry)));
+    sc->stack_blocks = g_extend_blocks;
     HIPCHECK(hipMemcpy(sc->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(sc->d_prims_bvh, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
     // generic sibling pairs (112 B) and, for all-sphere scenes, 48-B spheres
@@ -647,7 +704,7 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
         hipLaunchKernelGGL(k_load_rays, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_o, d_d, m, w.q(0));
         ExtendOut eo; eo.prim = w.hit_prim; eo.t = d_t; eo.tp = w.hit_tp; eo.tn = nullptr; eo.hit = d_h; eo.trace = 1;
         if (hipMemsetAsync(w.counts, 0, (size_t)w.depth_cap * 2 * sizeof(uint32_t), st) != hipSuccess) { ret = fail(RT_E_HIP, "memset failed"); break; }
-        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, w.counts + w.depth_cap, st, m);
+        ret = launch_extend(sc, algorithm, w.q(0), nullptr, m, tmin, tmax, eo, w.counts + w.depth_cap, w.stats, st, m);
         if (ret) break;
         if (out_prim) e = hipMemcpyAsync(out_prim + off, w.hit_prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && out_t) e = hipMemcpyAsync(out_t + off, d_t, m * sizeof(double), hipMemcpyDeviceToHost, st);
@@ -701,7 +758,10 @@ int rt_scene_reserve(rt_scene* sc, uint32_t image_width, uint32_t image_height, 
 
 int rt_render_device(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
                      uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats) {
-    return render_impl(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_out_sum, stream ? (hipStream_t)stream : g_stream, stats);
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    // NULL is the legacy default stream: the library's own stream does not synchronise with it implicitly, so wait here
+    if (!stream) HIPCHECK(hipStreamSynchronize(nullptr));
+    return render_dynamic(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_out_sum, stream ? (hipStream_t)stream : g_stream, stats);
 }
 
 int rt_render(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
@@ -710,7 +770,7 @@ int rt_render(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begi
     const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
     double* d_fb = nullptr;
     HIPCHECK(hipMalloc(&d_fb, (WH ? WH : 1) * 3 * sizeof(double)));
-    int rc = render_impl(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_fb, g_stream, stats);
+    int rc = render_dynamic(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_fb, g_stream, stats);
     if (rc == RT_OK) {
         hipError_t e = hipMemcpy(out_sum, d_fb, WH * 3 * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RT_E_HIP, "framebuffer readback failed: %s", hipGetErrorString(e));

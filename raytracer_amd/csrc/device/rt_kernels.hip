@@ -290,6 +290,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     const uint32_t refill_min = ((tune >> 16) & 0xffu) > 64u ? 64u : ((tune >> 16) & 0xffu);   // a fully idle wave always refills
     __shared__ uint4 s_stk[RT_STK][RT_BLOCK];       // {far_d lo, far_d hi, a, b | flag}: one 16-byte access per push / pop
     const uint32_t n = count ? *count : (uint32_t)n_fixed;
+    // one lane per ray is all a short queue can use: surplus blocks leave before they touch the fetch counter (each wave's
+    // atomic on that one word costs more than the traversal of a few hundred rays); block 0 always stays
+    if (blockIdx.x != 0 && (uint64_t)blockIdx.x * RT_BLOCK >= n) return;
     const uint32_t T = gridDim.x * RT_BLOCK, tx = threadIdx.x, lane = tx & 63;
     StackEntry* my_spill = spill + (blockIdx.x * RT_BLOCK + tx);
     uint32_t chunk = n / ((T >> 6) * 4u);

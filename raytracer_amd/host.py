@@ -279,8 +279,9 @@ class Camera:
         st = F.RtStats()
         algo = world.ALGOS[world.algorithm]
         if d_out is not None:
-            _hip_check(F.hip_lib().rt_render_device(world._dev, C.byref(self.c), algo, s_begin, s_count, self.max_depth, seed,
-                                                    C.c_void_p(d_out), C.c_void_p(stream or 0), C.byref(st)))
+            fn = F.hip_lib().rt_render_device
+            _hip_check(fn(world._dev, C.byref(self.c), algo, s_begin, s_count, self.max_depth, seed,
+                          C.c_void_p(d_out), C.c_void_p(stream or 0), C.byref(st)))
             return None, st.as_dict()
         out = np.empty((self.image_height, self.image_width, 3), np.float64)
         _hip_check(F.hip_lib().rt_render(world._dev, C.byref(self.c), algo, s_begin, s_count, self.max_depth, seed,

@@ -55,3 +55,27 @@ def test_spp_split_reduce_world_size_2():
     assert all(p.exitcode == 0 for p in procs)
     same_image, same_rays = q.get()
     assert same_image and same_rays
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(monkeypatch):
+    """bench.py --gpus N without a launcher builds a torch.distributed.run command for N ranks on 127.0.0.1 (and does so
+    before importing torch); under a launcher a WORLD_SIZE that contradicts --gpus is an error."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
+        bench.main()

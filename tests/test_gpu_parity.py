@@ -350,3 +350,70 @@ def test_full_size_properties_dragon_4k(gpu, monkeypatch):
     for k in ("scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb"):
         assert sp[k] == st[k], k
     w.close()
+
+
+@pytest.mark.parametrize("max_depth", [0, 1, 2])
+def test_shallow_depths_match_oracle(gpu, max_depth):
+    """camera.rs:155-157: depth 0 returns black before world.hit is called (no counters but primary_rays); depth 1 and 2 end
+    every path after one / two scatters."""
+    w = weekend_mixed()
+    osc = setup_pair(w, "bvh")
+    w.upload()
+    cam = Camera(w.filename, image_width=96, samples_per_pixel=3, max_depth=max_depth)
+    img, st = cam.render(w, seed=9)
+    ref, cst = osc.render(O.camera_from_rt(cam.c), "bvh", 0, 3, max_depth, seed=9, nthreads=4)
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb"):
+        assert st[k] == cst[k], f"depth {max_depth}, counter {k}: gpu {st[k]} oracle {cst[k]}"
+    if max_depth == 0:
+        assert not img.any() and not ref.any() and st["scatter_rays"] == 0 and st["intersection_checks"] == 0
+    else:
+        assert np.max(np.abs(img - ref) / np.maximum(np.abs(ref), 1e-300)) <= RADIANCE_RTOL
+    w.close()
+
+
+def test_max_depth_limit_is_an_error_not_a_fault(gpu):
+    from raytracer_amd.host import RtError
+    w = load_world("simple_fuzzy_metal"); w.algorithm = "bvh"; w.init().upload()
+    cam = Camera(w.filename, image_width=32, samples_per_pixel=1, max_depth=0xFFFFFFFE)
+    with pytest.raises(RtError, match="max_depth"):
+        cam.render(w)
+    w.close()
+
+
+def test_set_bvh_rejects_trees_the_pair_tables_cannot_address(gpu):
+    """rt_scene_set_bvh validates what the kernels trust: sibling adjacency AND the odd index of every left child
+    (bvh.rs:167-169 numbers children 2k+1, 2k+2; the persistent kernel's pair tables are addressed by (left+1)/2)."""
+    import ctypes as C
+    from raytracer_amd import _ffi as F
+    w = load_world("simple_fuzzy_metal"); w.algorithm = "bvh"; w.init().upload()
+    nodes, order = w.bvh.nodes(), w.bvh.order(len(w))
+    assert not nodes[0]["is_leaf"] and nodes[0]["left"] == 1
+    # the same tree with an unused node spliced in at index 1: children of the root become (2, 3) — adjacent, but left is even
+    bad = np.zeros(len(nodes) + 1, dtype=nodes.dtype)
+    bad[0] = nodes[0]; bad[2:] = nodes[1:]; bad[1] = nodes[1]
+    for nd in bad:
+        if not nd["is_leaf"]:
+            nd["left"] += 1; nd["right"] += 1
+    hip = F.hip_lib()
+    rc = hip.rt_scene_set_bvh(w._dev, bad.ctypes.data_as(C.POINTER(F.RtBvhNode)), len(bad), order.ctypes.data_as(C.POINTER(C.c_uint32)), len(order))
+    assert rc == -1 and b"even index" in hip.rt_last_error()
+    # the scene is still usable with the good tree
+    rc = hip.rt_scene_set_bvh(w._dev, nodes.ctypes.data_as(C.POINTER(F.RtBvhNode)), len(nodes), order.ctypes.data_as(C.POINTER(C.c_uint32)), len(order))
+    assert rc == 0
+    w.close()
+
+
+def test_extend_blocks_raised_after_set_bvh_stays_inside_the_stack(gpu, monkeypatch):
+    """The continuation stack is sized when the tree is installed; a later rt_init with a larger RT_EXTEND_BLOCKS must not
+    launch more blocks than it was sized for: same image, same counters."""
+    import raytracer_amd as rt
+    w = load_world("dragon_res4")
+    monkeypatch.setenv("RT_EXTEND_BLOCKS", "256"); rt.init(0)
+    w.algorithm = "bvh"; w.init().upload()
+    cam = Camera(w.filename, image_width=160, samples_per_pixel=2)
+    a, sa = cam.render(w, seed=2)
+    monkeypatch.setenv("RT_EXTEND_BLOCKS", "4096"); rt.init(0)
+    b, sb = cam.render(w, seed=2)
+    monkeypatch.setenv("RT_EXTEND_BLOCKS", "2048"); rt.init(0)
+    assert np.array_equal(a, b) and sa["intersection_checks"] == sb["intersection_checks"] and sa["scatter_rays"] == sb["scatter_rays"]
+    w.close()
