@@ -141,6 +141,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        print(f"[bench] set-up done in {time.time() - t0:.1f} s; {a.warmup} warm-up + {a.steps} timed steps ...", file=sys.stderr, flush=True)
     for _ in range(a.warmup):
         step()
     fence()
@@ -193,6 +195,7 @@ def main():
             pmc = pmc_passes(a)
         out["roofline"] = roofline(counts, pmc)
         if world == 1 and not a.no_cpu_baseline:
+            print("[bench] CPU baseline (oracle, 1 core, then all cores) ...", file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline(w, cam_name, a)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out), flush=True)
@@ -243,6 +246,7 @@ def pmc_passes(a):
         d = os.path.join(tmp, name)
         cmd = [prof, "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", name, "--"] + child
         t0 = time.time()
+        print(f"[bench] rocprofv3 --pmc pass '{name}' ({ctrs}) ...", file=sys.stderr, flush=True)
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
             try:
