@@ -314,7 +314,7 @@ def roofline(c, pmc):
                            "clock_GHz_profiled": (k["GRBM_GUI_ACTIVE"] / 8.0 / pmc["kernel_ns"]) if k.get("GRBM_GUI_ACTIVE") and pmc.get("kernel_ns") else None}})
         if k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
             cal, cal_src = fetch_calibration()
-            fetch_b = k["FETCH_SIZE"] * 1e3 * cal * scale; write_b = k["WRITE_SIZE"] * 1e3 * scale
+            fetch_b = k["FETCH_SIZE"] * 1024.0 * cal * scale; write_b = k["WRITE_SIZE"] * 1024.0 * scale      # counter unit: KiB
             r["traffic"] = (fetch_b + write_b) / launches
             r["hbm"] = {"bound": "hbm", "achieved": (fetch_b + write_b) / ext_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": (fetch_b + write_b) / ext_s / 1e9 / HBM_PEAK_GBPS,

@@ -368,6 +368,67 @@ struct Builder {
     }
 };
 
+/* ---------------------------------------------------------------- BVH build, second form (BvhSahPosition only)
+ * The literal get_split above re-folds both sides of every candidate split (bvh.rs:148-160), O(len^2) box unions per node,
+ * which does not end for meshes much beyond 10^4 triangles.  This form produces the same nodes from the same definitions in
+ * O(len log len) per node; tests/test_oracle_sweep.py holds it to byte equality with the literal form on every scene the
+ * literal form finishes, and the larger meshes' trees (res3, the 764 704-triangle bench mesh) come from here.
+ *
+ * Why it is the same tree, not merely a similar one:
+ *  - candidate `split` on an axis costs SA(fold(sorted[..split])) * split + SA(fold(sorted[split..])) * (count - split), where
+ *    fold chains AABB::add = per-coordinate f64::min / f64::max (hittable_list.rs:123-133, aabb.rs:134-147);
+ *  - before[s] below IS the reference's left fold (same chain, same order), bit for bit;
+ *  - after[s] chains the same operands from the other end.  min/max of non-NaN doubles return one of their operands and the
+ *    value does not depend on grouping; only the sign of a zero can (min(-0, +0)).  A zero of either sign gives the same
+ *    surface area up to the sign of a zero product, so `h < best` (bvh.rs:127,155) decides identically;
+ *  - nothing from after[] is stored: the two children are rebuilt with the literal new_leaf (left-to-right fold) on the
+ *    node's final order, which is what bvh.rs:152-153 built from axis_objects for the winning (axis, split). */
+struct SweepBuilder {
+    orc_scene& sc; Builder lit;
+    std::vector<uint32_t> by_axis;
+    std::vector<AABB> before, after;
+    explicit SweepBuilder(orc_scene& s) : sc(s), lit(s, ORC_BVH_SAH_POSITION) {}
+
+    bool get_split(const BvhNode& self, uint32_t* objs, size_t len, BvhNode& bl, BvhNode& br) {
+        double best_heuristic = surface_area(self.aabb) * (double)self.count;          /* bvh.rs:101 */
+        bool have = false; unsigned best_axis = 0; size_t best_split = 0;
+        if (len > 1) {
+            by_axis.resize(len); before.resize(len); after.resize(len + 1);
+            for (unsigned axis = 0; axis < 3; ++axis) {                                /* :104 */
+                std::copy(objs, objs + len, by_axis.begin());                          /* :105-106 */
+                lit.sort_axis(by_axis.data(), len, axis);                              /* :107-112 */
+                before[1] = sc.prim_aabb[by_axis[0]];
+                for (size_t s = 2; s < len; ++s) before[s] = aabb_union(before[s - 1], sc.prim_aabb[by_axis[s - 1]]);
+                after[len - 1] = sc.prim_aabb[by_axis[len - 1]];
+                for (size_t s = len - 1; s-- > 1;) after[s] = aabb_union(sc.prim_aabb[by_axis[s]], after[s + 1]);
+                for (size_t split = 1; split < len; ++split) {                         /* :125 */
+                    double lh = surface_area(before[split]) * (double)split;           /* :152-154 */
+                    double rh = surface_area(after[split]) * (double)(self.count - split);
+                    double h = lh + rh;
+                    if (h < best_heuristic) { best_heuristic = h; have = true; best_axis = axis; best_split = split; }   /* :155,127-131 */
+                }
+            }
+        }
+        lit.sort_axis(objs, len, best_axis);                                           /* :136-140 */
+        if (have) {
+            bl = lit.new_leaf(0, self.first, best_split, objs);
+            br = lit.new_leaf(best_split, self.first, self.count - best_split, objs);
+        }
+        return have;
+    }
+    void sub_divide(BvhNode& self) {                                                   /* :162-180 */
+        BvhNode l, r;
+        if (get_split(self, sc.bvh_objects.data() + self.first, self.count, l, r)) {
+            self.left = sc.node_pointer + 1;
+            self.right = sc.node_pointer + 2;
+            sc.node_pointer += 2;
+            sub_divide(l); sc.nodes[self.left] = l;
+            sub_divide(r); sc.nodes[self.right] = r;
+            self.is_leaf = false;
+        }
+    }
+};
+
 /* ---------------------------------------------------------------- traversal */
 struct Trace {
     const orc_scene& sc; Counters& data;
@@ -628,6 +689,20 @@ int orc_build_bvh(orc_scene* sc, int mode) {                   /* Bvh::new bvh.r
     if (n == 0) { sc->have_bvh = false; return -1; }           /* reference: nodes.first() is None -> every ray misses */
     Builder b(*sc, mode);
     BvhNode root = b.new_leaf(0, 0, n, sc->bvh_objects.data());
+    b.sub_divide(root);
+    sc->nodes[0] = root;
+    sc->have_bvh = true;
+    return 0;
+}
+int orc_build_bvh_sweep(orc_scene* sc) {                       /* Bvh::new bvh.rs:19-26, BvhSahPosition through SweepBuilder */
+    size_t n = sc->prims.size();
+    sc->bvh_objects.resize(n);
+    for (size_t i = 0; i < n; ++i) sc->bvh_objects[i] = (uint32_t)i;
+    sc->nodes.assign(n * 4, node_default());
+    sc->node_pointer = 0; sc->bvh_mode = ORC_BVH_SAH_POSITION;
+    if (n == 0) { sc->have_bvh = false; return -1; }
+    SweepBuilder b(*sc);
+    BvhNode root = b.lit.new_leaf(0, 0, n, sc->bvh_objects.data());
     b.sub_divide(root);
     sc->nodes[0] = root;
     sc->have_bvh = true;

@@ -52,6 +52,7 @@ def lib():
         L.orc_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_build_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.orc_build_bvh_sweep.argtypes = [C.c_void_p]
         L.orc_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_bvh_node_count.argtypes = [C.c_void_p]; L.orc_bvh_node_count.restype = C.c_uint32
         L.orc_get_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -83,8 +84,11 @@ class OracleScene:
         if getattr(self, "_h", None):
             lib().orc_scene_destroy(self._h); self._h = None
 
-    def build_bvh(self, mode="sah-position"):
-        rc = lib().orc_build_bvh(self._h, BVH_MODES[mode])
+    def build_bvh(self, mode="sah-position", sweep=False):
+        """sweep=True (sah-position only): the O(n log n)-per-node statement of the same build, for big meshes."""
+        if sweep and mode != "sah-position":
+            raise ValueError("the sweep builder restates BvhSahPosition only")
+        rc = lib().orc_build_bvh_sweep(self._h) if sweep else lib().orc_build_bvh(self._h, BVH_MODES[mode])
         if rc: raise RuntimeError(f"orc_build_bvh {rc}")
         return self
 
