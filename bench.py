@@ -340,7 +340,9 @@ def cpu_baseline(w, cam_name, a):
     from oracle import oracle_py as O
     from raytracer_amd import Camera
     osc = O.OracleScene(w.prims(), w.centroids(), w.materials())
-    osc.set_bvh(w.bvh.nodes(), w.bvh.order(len(w)))
+    t = time.perf_counter(); osc.build_bvh("sah-position", sweep=True); t_build = time.perf_counter() - t   # the oracle's own SAH build
+    on, oo = osc.get_bvh()
+    same_tree = on.tobytes() == w.bvh.nodes().tobytes() and bool((oo == w.bvh.order(len(w))).all())
     cam = Camera(cam_name, image_width=480, max_depth=a.max_depth)
     oc = O.camera_from_rt(cam.c)
     t = time.perf_counter(); _, c = osc.render(oc, "bvh", 0, 1, a.max_depth, seed=1, nthreads=1); d1 = time.perf_counter() - t
@@ -351,7 +353,8 @@ def cpu_baseline(w, cam_name, a):
     nth = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
     t = time.perf_counter(); _, c2 = osc.render(oc, "bvh", 1, spp, a.max_depth, seed=1, nthreads=nth); dt2 = time.perf_counter() - t
     rays2 = c2["primary_rays"] + c2["scatter_rays"]
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "bvh_build_seconds": round(t_build, 2),
+            "bvh_identical_to_gpu_path": same_tree,
             "sample": f"same scene/BVH/camera at 480x{cam.image_height}, {spp} spp, depth {a.max_depth}: {rays} rays in {dt:.1f} s on 1 host core "
                       f"(host has {os.cpu_count()} logical CPUs; the reference is single-threaded by construction)",
             "all_cores": {"value": rays2 / dt2 / 1e6, "unit": "Mrays/s", "cores": nth, "note": "rows split over std::threads; not reference behaviour"}}

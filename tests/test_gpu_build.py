@@ -1,5 +1,6 @@
-"""Bvh::new on the GPU (rt_bvh_build) against the host builder, which tests/test_host.py pins against the
-oracle's literal restatement of bvh.rs:19-180: nodes, numbering and object order byte for byte."""
+"""Bvh::new on the GPU (rt_bvh_build) against the host builder and against the oracle (its literal
+restatement of bvh.rs:19-180 up to res4, its sweep form above that — tests/test_oracle_sweep.py): nodes, numbering and object
+order byte for byte."""
 import time
 
 import numpy as np
@@ -7,7 +8,7 @@ import pytest
 
 from raytracer_amd import HittableList
 
-from .util import load_world, weekend_mixed
+from .util import load_world, oracle_of, weekend_mixed
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +31,8 @@ def test_gpu_bvh_equals_host_bvh(gpu, scene):
     for f in ("is_leaf", "left", "right", "first", "count"):
         assert np.array_equal(dev[0][f], host[0][f]), f
     assert dev[0].tobytes() == host[0].tobytes(), "box planes differ"
+    on, oo = oracle_of(w).build_bvh("sah-position", sweep=scene == "dragon_res3").get_bvh()
+    assert on.tobytes() == dev[0].tobytes() and np.array_equal(oo, dev[1]), "GPU-built tree differs from the oracle's"
 
 
 def test_gpu_bvh_single_object_and_duplicates(gpu):
@@ -56,4 +59,6 @@ def test_gpu_bvh_full_size_mesh_and_time(gpu):
     w.gpu_build = True; w.init()                         # first call pays hipCUB kernel loading
     t = time.time(); w.init(); t_dev = time.time() - t
     assert (w.bvh.nodes().tobytes(), w.bvh.order(len(w)).tobytes(), w.bvh.depth) == host
+    on, oo = oracle_of(w).build_bvh("sah-position", sweep=True).get_bvh()
+    assert on.tobytes() == host[0] and oo.tobytes() == host[1], "the bench mesh's tree differs from the oracle's sweep build"
     print(f"\nBVH build, 764704 triangles: host {t_host:.2f} s, GPU {t_dev:.3f} s")

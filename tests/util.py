@@ -43,8 +43,13 @@ def setup_pair(world, algorithm, bvh_mode="sah-position", grid_size=25.0, oracle
     if algorithm == "bvh":
         if oracle_own_build:
             osc.build_bvh(bvh_mode)
-        else:  # scenes too big for the oracle's literal O(N^2) builder: import the (separately pinned) layout
-            osc.set_bvh(world.bvh.nodes(), world.bvh.order(len(world)))
+        else:  # meshes too big for the oracle's literal O(N^2) builder: its sweep form (tests/test_oracle_sweep.py holds the two
+               # to byte equality wherever the literal one finishes).  The product's tree is never imported into the oracle here.
+            assert bvh_mode == "sah-position"
+            osc.build_bvh(bvh_mode, sweep=True)
+            nodes, order = osc.get_bvh()
+            assert nodes.tobytes() == world.bvh.nodes().tobytes() and np.array_equal(order, world.bvh.order(len(world))), \
+                "the product's BVH differs from the oracle's"
     elif algorithm == "grid":
         osc.build_grid(grid_size)
     return osc

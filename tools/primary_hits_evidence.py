@@ -13,7 +13,7 @@ fn = "scenes/dragon_recon/dragon_vrip_res3.ply"
 w = HittableList.from_ply(fn, subdivide=2); w.algorithm = "bvh"; w.init(); w.upload()
 cam = Camera(fn, image_width=3840, samples_per_pixel=1)
 W, H = cam.image_width, cam.image_height
-osc = O.OracleScene(w.prims(), w.centroids(), w.materials()); osc.set_bvh(w.bvh.nodes(), w.bvh.order(len(w)))
+osc = O.OracleScene(w.prims(), w.centroids(), w.materials()); osc.build_bvh("sah-position", sweep=True)
 tot = {"rays": 0, "hits": 0, "mismatch_hit": 0, "mismatch_prim": 0, "mismatch_t_bits": 0, "mismatch_tp_bits": 0, "mismatch_ray_bits": 0}
 cnt_g = {}; cnt_o = {}; t0 = time.time()
 for j0 in range(0, H, 120):                                    # bands of rows: bounded memory, progress lines

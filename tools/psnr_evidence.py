@@ -19,7 +19,7 @@ for name, spp in zip(args[0::2], map(int, args[1::2])):
     w.algorithm = "bvh"; w.init(); w.upload()
     cam = Camera(fn, image_width=480, samples_per_pixel=spp)
     t = time.time(); img, st = cam.render(w, seed=11); t_gpu = time.time() - t
-    osc = O.OracleScene(w.prims(), w.centroids(), w.materials()); osc.set_bvh(w.bvh.nodes(), w.bvh.order(len(w)))
+    osc = O.OracleScene(w.prims(), w.centroids(), w.materials()); osc.build_bvh("sah-position", sweep=True)
     oc = O.camera_from_rt(cam.c); H = cam.image_height
     ref = np.zeros_like(img); t = time.time(); rays = 0
     for r0 in range(0, H, 10):                                   # bands of rows: progress lines for the harness

@@ -25,7 +25,7 @@ for name, algo, gsize, spp in jobs:
     cam = Camera(fn, image_width=480, samples_per_pixel=spp)
     img, st = cam.render(w, seed=7)
     osc = O.OracleScene(w.prims(), w.centroids(), w.materials())
-    if algo == "bvh": osc.set_bvh(w.bvh.nodes(), w.bvh.order(len(w)))
+    if algo == "bvh": osc.build_bvh("sah-position", sweep=True)
     if algo == "grid": osc.build_grid(float(gsize))
     oc = O.camera_from_rt(cam.c); H = cam.image_height
     ref = np.zeros_like(img); cnt = {}; t = time.time()
