@@ -147,6 +147,18 @@ int rt_render(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint
 int rt_render_device(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
                      uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats);
 
+/* No counterpart in the reference.  rt_render_device for callers that cannot allocate (code under HIP graph capture set-up,
+ * tight serving loops, harnesses that forbid hipMalloc): same arguments, same result bit for bit, but the ray queues, hit
+ * queue, per-path radiance records, queue lengths and counters live in a static device array of 50 MB that each GPU holds
+ * from library load to process end, and the call makes no hipMalloc / hipFree / hipHostMalloc / event creation.  Limits
+ * (RT_E_LIMIT beyond them): image_width * image_height <= 262144 pixels (samples are batched to fit 262144 paths in flight),
+ * max_depth <= 1022.  Queue lengths are not read back: all max_depth bounces are launched, the ones that find an empty queue
+ * do nothing.  Per-kernel times in rt_stats stay 0.  Every call on a GPU uses that GPU's one array: calls that overlap on one
+ * GPU (two host threads, two processes do not share it) race; the scene must have been set up (rt_scene_set_bvh / _grid)
+ * before, since those calls do allocate. */
+int rt_render_device_noalloc(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                             uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats);
+
 /* No counterpart in the reference (its render owns no buffers that outlive a call).  Sizes and allocates, now, the per-scene
  * workspace that rt_render / rt_render_device of an image_width x image_height image with s_count samples per call would
  * allocate on first use (ray queues, hit queue, per-path radiance: 196 B per path in flight, up to 75 % of the free HBM), so

@@ -60,7 +60,7 @@ class RtStats(C.Structure):
 
 # every symbol include/rt_hip.h declares (tests check the library exports exactly these)
 RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_scene_build_grid", "rt_scene_get_grid", "rt_trace",
-                  "rt_generate", "rt_render", "rt_render_device", "rt_scene_reserve", "rt_scene_destroy", "rt_last_error"]
+                  "rt_generate", "rt_render", "rt_render_device", "rt_render_device_noalloc", "rt_scene_reserve", "rt_scene_destroy", "rt_last_error"]
 
 _hip = None
 _host = None
@@ -102,6 +102,8 @@ def hip_lib():
     lib.rt_render_device.argtypes = [C.c_void_p, P(RtCamera), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_void_p, C.c_void_p, P(RtStats)]
     lib.rt_render_device.restype = C.c_int
+    lib.rt_render_device_noalloc.argtypes = lib.rt_render_device.argtypes
+    lib.rt_render_device_noalloc.restype = C.c_int
     lib.rt_scene_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]; lib.rt_scene_reserve.restype = C.c_int
     lib.rt_scene_destroy.argtypes = [C.c_void_p]; lib.rt_scene_destroy.restype = None
     lib.rt_last_error.argtypes = []; lib.rt_last_error.restype = C.c_char_p

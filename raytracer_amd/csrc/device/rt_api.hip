@@ -18,6 +18,16 @@ struct GridResult { rt_grid_desc desc; double* cell_aabb; unsigned long long* ce
 int build_grid(const rt_prim* prims, uint32_t n, double s, GridResult& out, hipStream_t st, std::string& err);
 }
 
+// Workspace of rt_render_device_noalloc (include/rt_hip.h): ray queues, hit queue, per-path radiance, queue lengths and
+// counters for up to RT_NOALLOC_MAX_PATHS paths in flight, in a static device array instead of hipMalloc memory.  Each GPU the
+// library runs on holds its own copy (50 MB) until the process ends.  Host code never uses the name `scratch` as an address:
+// rt_init looks the device address up with hipGetSymbolAddress, once per device, and the kernels receive pointers derived
+// from that, exactly as they receive the hipMalloc'd workspace in rt_render_device.
+#define RT_NOALLOC_MAX_PATHS (1u << 18)
+#define RT_NOALLOC_MAX_DEPTH 1022u
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_PATHS * 196u + (size_t)(RT_NOALLOC_MAX_DEPTH + 2u) * 8u + 4096u)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+
 namespace {
 
 thread_local std::string g_err;
@@ -33,9 +43,10 @@ bool g_inited = false;
 int g_device = -1;
 bool g_profiling = false;
 hipStream_t g_stream = nullptr;       // the current device's stream (g_dev[g_device].stream)
-// what rt_init keeps per device: the library's stream and two events for the pipelined queue-length read-back
+// what rt_init keeps per device: the library's stream, two events for the pipelined queue-length read-back, and the device
+// address of the static workspace of rt_render_device_noalloc (every GPU holds its own copy of the array at its own address)
 #define RT_MAX_DEVICES 64
-struct DevState { hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+struct DevState { hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; unsigned char* scratch = nullptr; };
 DevState g_dev[RT_MAX_DEVICES];
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
 uint32_t g_stream_blocks = 4096;
@@ -74,7 +85,7 @@ struct Workspace {
     unsigned long long* stats = nullptr;
     uint32_t* h_count = nullptr; // pinned, 16 words: ring of the last queue lengths read back
     unsigned long long* h_stats = nullptr;
-    bool is_static = false;      // a view of memory the workspace does not own: nothing to free, no pinned host words
+    bool is_static = false;      // a view of the static device array (rt_render_device_noalloc): nothing to free, no pinned host words
     void release() {
         if (is_static) return;
         for (int i = 0; i < 2; ++i) { if (qbuf[i]) (void)hipFree(qbuf[i]); if (qid[i]) (void)hipFree(qid[i]); qbuf[i] = nullptr; qid[i] = nullptr; }
@@ -246,18 +257,18 @@ int size_workspace(rt_scene* sc, uint64_t WH, uint32_t s_count, uint32_t max_dep
     return RT_OK;
 }
 
-// The bounce loop.  `w` is the workspace the call runs in (the scene's own, sized from free HBM by size_workspace);
-// k = samples per pixel per batch, already fitted to w.cap.
+// The bounce loop.  `w` is the workspace the call runs in: the scene's own (sized from free HBM by size_workspace) or a view of
+// the static device array (rt_render_device_noalloc); k = samples per pixel per batch, already fitted to w.cap.
 // Queue lengths: every kernel strides over *count in device memory, so the host needs them only to stop early and to give
 // short queues a small grid.  The read-back is pipelined: bounce b+1 is launched before the host looks at the length bounce b
 // produced (an empty queue costs two launches that find nothing to do), so the GPU never waits for the host between bounces;
 // a queue never grows (a path scatters into at most one ray), so the last length read is an upper bound for the launch shape.
-// Without pinned host words nothing is read back and all max_depth bounces are launched.
+// Without pinned host words (static workspace) nothing is read back and all max_depth bounces are launched.
 int render_impl(rt_scene* sc, Workspace& w, uint32_t k, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
                 uint64_t seed, double* d_fb, hipStream_t st, rt_stats* stats) {
     const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
     int rc = RT_OK;
-    const bool profiling = g_profiling && !w.is_static;
+    const bool profiling = g_profiling && !w.is_static;                  // event pools grow on demand: not in the no-allocation call
     const bool readback = w.h_count != nullptr;
     DevState& dev = g_dev[g_device];
 
@@ -394,6 +405,11 @@ int rt_init(int device) {
         HIPCHECK(hipStreamCreateWithFlags(&dv.stream, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&dv.ev[0], hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&dv.ev[1], hipEventDisableTiming));
+        // rt_render_device_noalloc's workspace: the array's name is a host-side stand-in, its device address is looked up once
+        // per device, with that device current
+        void* p = nullptr;
+        HIPCHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        dv.scratch = (unsigned char*)p;
     }
     g_stream = dv.stream; g_device = device;
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
@@ -762,6 +778,35 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t
     // NULL is the legacy default stream: the library's own stream does not synchronise with it implicitly, so wait here
     if (!stream) HIPCHECK(hipStreamSynchronize(nullptr));
     return render_dynamic(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_out_sum, stream ? (hipStream_t)stream : g_stream, stats);
+}
+
+int rt_render_device_noalloc(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                             uint64_t seed, double* d_out_sum, void* stream, rt_stats* stats) {
+    { const int rca = check_render_args(sc, cam, algorithm, max_depth, d_out_sum); if (rca) return rca; }
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    if (WH > RT_NOALLOC_MAX_PATHS) return fail(RT_E_LIMIT, "rt_render_device_noalloc: image of %llu pixels is above the static workspace's %u paths", (unsigned long long)WH, (unsigned)RT_NOALLOC_MAX_PATHS);
+    if (max_depth > RT_NOALLOC_MAX_DEPTH) return fail(RT_E_LIMIT, "rt_render_device_noalloc: max_depth %u is above the static workspace's %u", max_depth, (unsigned)RT_NOALLOC_MAX_DEPTH);
+    unsigned char* base = g_dev[g_device].scratch;                  // device address from hipGetSymbolAddress (rt_init), never the array's name
+    if (!base) return fail(RT_E_STATE, "rt_init() did not resolve the static workspace on device %d", g_device);
+    Workspace w; w.is_static = true;
+    const uint64_t cap = RT_NOALLOC_MAX_PATHS;
+    w.cap = cap; w.depth_cap = RT_NOALLOC_MAX_DEPTH + 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char* p = base + off; off += (bytes + 255) & ~(size_t)255; return p; };
+    w.qbuf[0] = (double*)take(cap * 9 * sizeof(double)); w.qbuf[1] = (double*)take(cap * 9 * sizeof(double));
+    w.rad = (double*)take(cap * 3 * sizeof(double));
+    w.hit_tp = (double*)take(cap * sizeof(double)); w.hit_tn = (double*)take(cap * sizeof(double));
+    w.qid[0] = (uint32_t*)take(cap * sizeof(uint32_t)); w.qid[1] = (uint32_t*)take(cap * sizeof(uint32_t));
+    w.hit_prim = (int32_t*)take(cap * sizeof(int32_t));
+    w.counts = (uint32_t*)take((size_t)w.depth_cap * 2 * sizeof(uint32_t));
+    w.stats = (unsigned long long*)take(ST_N * sizeof(unsigned long long));
+    if (off > RT_NOALLOC_BYTES) return fail(RT_E_STATE, "static workspace layout (%zu B) exceeds the array (%zu B)", off, (size_t)RT_NOALLOC_BYTES);
+    uint64_t k64 = cap / WH; if (s_count && k64 > s_count) k64 = s_count;
+    if (s_count) { const uint64_t nb = (s_count + k64 - 1) / k64; k64 = (s_count + nb - 1) / nb; }   // equal batches
+    if (!stream) HIPCHECK(hipStreamSynchronize(nullptr));
+    // every queue, counter and record of the array that a batch reads is written by that batch first (counts and stats are
+    // cleared by render_impl); nothing is kept between calls
+    return render_impl(sc, w, (uint32_t)k64, cam, algorithm, s_begin, s_count, max_depth, seed, d_out_sum, stream ? (hipStream_t)stream : g_stream, stats);
 }
 
 int rt_render(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,

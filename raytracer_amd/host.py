@@ -268,10 +268,11 @@ class Camera:
         _hip_check(F.hip_lib().rt_generate(C.byref(self.c), seed, sample, pi.ctypes.data, pj.ctypes.data, len(pi), o.ctypes.data, d.ctypes.data))
         return o, d
 
-    def render(self, world, seed=1, s_begin=0, s_count=None, d_out=None, stream=None):
+    def render(self, world, seed=1, s_begin=0, s_count=None, d_out=None, stream=None, noalloc=False):
         """Camera::render (camera.rs:53-82) minus the text output: returns (sum[H,W,3], stats dict).
 
-        With ``d_out`` (a device pointer to W*H*3 doubles) the framebuffer stays in HBM and None is returned for it.
+        With ``d_out`` (a device pointer to W*H*3 doubles) the framebuffer stays in HBM and None is returned for it;
+        ``noalloc`` selects rt_render_device_noalloc (static workspace, no allocation inside the call).
         """
         if world._dev is None:
             raise RtError("world.upload() first")
@@ -279,7 +280,7 @@ class Camera:
         st = F.RtStats()
         algo = world.ALGOS[world.algorithm]
         if d_out is not None:
-            fn = F.hip_lib().rt_render_device
+            fn = F.hip_lib().rt_render_device_noalloc if noalloc else F.hip_lib().rt_render_device
             _hip_check(fn(world._dev, C.byref(self.c), algo, s_begin, s_count, self.max_depth, seed,
                           C.c_void_p(d_out), C.c_void_p(stream or 0), C.byref(st)))
             return None, st.as_dict()
