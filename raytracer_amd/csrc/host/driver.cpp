@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 namespace rth {
 
@@ -28,6 +31,8 @@ static const char* kHelp =
     "      --gpu-build              Build the (default, SAH position) BVH on the GPU instead of on the host (addition)\n"
     "      --binary-ppm             Write the image as binary PPM (P6) instead of P3 text (addition)\n"
     "      --device <N>             GPU index [default: 0] (addition)\n"
+    "      --gpus <N>               Split the samples over N GPUs, one forked worker process each, partial sums added in rank\n"
+    "                               order (addition; with an explicit --device every worker uses that GPU: rehearsal) [default: 1]\n"
     "      --subdivide <L>          Split every PLY triangle into 4, L times (addition; synthetic meshes)\n"
     "      --output-dir <DIR>       Where the .ppm and stats.csv go [default: output]\n"
     "  -h, --help                   Print help\n";
@@ -59,7 +64,8 @@ bool parse_cli(int argc, const char* const* argv, Cli& out, std::string& err) {
         else if (key == "--spp") { if (!need(i, "--spp", v)) return false; out.spp = atoi(v.c_str()); if (out.spp < 1) { err = "error: --spp must be >= 1"; return false; } }
         else if (key == "--max-depth") { if (!need(i, "--max-depth", v)) return false; out.max_depth = atoi(v.c_str()); if (out.max_depth < 0) { err = "error: --max-depth must be >= 0"; return false; } }
         else if (key == "--seed") { if (!need(i, "--seed", v)) return false; out.seed = strtoull(v.c_str(), nullptr, 10); }
-        else if (key == "--device") { if (!need(i, "--device", v)) return false; out.device = atoi(v.c_str()); }
+        else if (key == "--device") { if (!need(i, "--device", v)) return false; out.device = atoi(v.c_str()); out.device_given = true; }
+        else if (key == "--gpus") { if (!need(i, "--gpus", v)) return false; out.gpus = atoi(v.c_str()); if (out.gpus < 1 || out.gpus > 64) { err = "error: --gpus must be in 1..64"; return false; } }
         else if (key == "--subdivide") { if (!need(i, "--subdivide", v)) return false; out.subdivide = atoi(v.c_str()); if (out.subdivide < 0 || out.subdivide > 4) { err = "error: --subdivide must be in 0..4"; return false; } }
         else if (key == "--binary-ppm") out.binary_ppm = true;
         else if (key == "--gpu-build") out.gpu_build = true;
@@ -147,6 +153,56 @@ bool write_stats_csv(const std::string& path, const RunStats& s, std::string& er
     return ok;
 }
 
+// dist.py's spp_range: global sample indices [begin, begin+count) of `rank`; remainders go to the lowest ranks
+void spp_range(uint32_t rank, uint32_t world, uint32_t spp, uint32_t& begin, uint32_t& count) {
+    const uint32_t base = spp / world, rem = spp % world;
+    begin = rank * base + (rank < rem ? rank : rem);
+    count = base + (rank < rem ? 1u : 0u);
+}
+
+namespace {
+struct Accel { bool have_bvh = false, have_grid = false; Bvh bvh; Grid grid; };
+
+// The device part of world.init() + cam.render() for samples [s_begin, s_begin + s_count) on one GPU: upload, flatten (or
+// build on the GPU with --gpu-build), rt_render.  `sum` receives W*H*3 partial sums.
+int render_slice(const Cli& cli, const Scene& scene, const Accel& acc, const rt_camera& rc, uint32_t max_depth, bool draw_boxes, int device,
+                 uint32_t s_begin, uint32_t s_count, double* sum, rt_stats* st, double* init_seconds, std::string& err) {
+    auto start = std::chrono::steady_clock::now();
+    if (rt_init(device) != RT_OK) { err = rt_last_error(); return 3; }
+    rt_scene* dev = rt_scene_create(scene.prims.data(), (uint32_t)scene.prims.size(), scene.mats.data(), (uint32_t)scene.mats.size());
+    if (!dev) { err = rt_last_error(); return 3; }
+    auto fail_hip = [&]() { err = rt_last_error(); rt_scene_destroy(dev); return 3; };
+    if (rt_scene_set_options(dev, draw_boxes ? (uint32_t)RT_OPT_DRAW_BOXES : 0u) != RT_OK) return fail_hip();
+    if (cli.algorithm == RT_ALGO_BVH) {
+        if (acc.have_bvh) {
+            if (rt_scene_set_bvh(dev, acc.bvh.nodes.data(), (uint32_t)acc.bvh.nodes.size(), acc.bvh.order.data(), (uint32_t)acc.bvh.order.size()) != RT_OK) return fail_hip();
+        } else {                                         // --gpu-build, default SAH mode
+            auto t = std::chrono::steady_clock::now();
+            Bvh bvh; const uint32_t n = (uint32_t)scene.prims.size();
+            bvh.nodes.resize(2 * (size_t)n + 1); bvh.order.resize(n);
+            uint32_t n_nodes = 0;
+            if (rt_bvh_build(scene.prims.data(), scene.centroids.data(), n, bvh.nodes.data(), &n_nodes, bvh.order.data(), &bvh.depth) != RT_OK) return fail_hip();
+            bvh.nodes.resize(n_nodes);
+            if (rt_scene_set_bvh(dev, bvh.nodes.data(), n_nodes, bvh.order.data(), n) != RT_OK) return fail_hip();
+            fprintf(stderr, "BVH constructed in %.2fs (%zu nodes, depth %u)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(), bvh.nodes.size(), bvh.depth);
+        }
+    } else if (cli.algorithm == RT_ALGO_GRID) {
+        if (acc.have_grid) {
+            if (rt_scene_set_grid(dev, &acc.grid.desc, acc.grid.cell_aabb.data(), acc.grid.cell_offset.data(), acc.grid.prim_list.data()) != RT_OK) return fail_hip();
+        } else {
+            auto t = std::chrono::steady_clock::now();
+            if (!(cli.grid_size >= 1.0)) { err = "grid size must be at least 1"; rt_scene_destroy(dev); return 1; }
+            if (rt_scene_build_grid(dev, cli.grid_size) != RT_OK) return fail_hip();
+            fprintf(stderr, "Grid constructed in %.2fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count());
+        }
+    }
+    *init_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    if (rt_render(dev, &rc, cli.algorithm, s_begin, s_count, max_depth, cli.seed, sum, st) != RT_OK) return fail_hip();
+    rt_scene_destroy(dev);
+    return 0;
+}
+} // namespace
+
 int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     std::string v = check_valid_options(cli.options);    // main.rs:25-27
     if (!v.empty()) { err = v; return 2; }
@@ -186,49 +242,86 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     const std::string out_filename = get_output_filename(cli);
     mkdir(cli.output_dir.c_str(), 0777);
 
-    if (rt_init(cli.device) != RT_OK) { err = rt_last_error(); return 3; }
     RunStats rs;
     rs.filename = cli.filename; rs.primitives = scene.prims.size(); rs.algorithm = algorithm_variant(cli.algorithm);
     rs.options = options_to_string(cli); rs.image_width = rc.image_width; rs.image_height = rc.image_height;
     rs.samples_per_pixel = cam.samples_per_pixel; rs.max_depth = cam.max_depth;
 
     auto start = std::chrono::steady_clock::now();
-    // world.init() main.rs:128 → hittable_list.rs:33-53 (host build, then flatten + upload)
-    rt_scene* dev = rt_scene_create(scene.prims.data(), (uint32_t)scene.prims.size(), scene.mats.data(), (uint32_t)scene.mats.size());
-    if (!dev) { err = rt_last_error(); return 3; }
-    if (rt_scene_set_options(dev, draw_boxes ? (uint32_t)RT_OPT_DRAW_BOXES : 0u) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
-    if (cli.algorithm == RT_ALGO_BVH) {
+    // world.init() main.rs:128 → hittable_list.rs:33-53, host part: the builders run once, before any worker exists
+    Accel acc;
+    if (cli.algorithm == RT_ALGO_BVH && !(cli.gpu_build && bvh_mode_of(cli.options) == BVH_SAH_POSITION)) {
         auto t = std::chrono::steady_clock::now();
-        Bvh bvh;
-        if (cli.gpu_build && bvh_mode_of(cli.options) == BVH_SAH_POSITION) {
-            const uint32_t n = (uint32_t)scene.prims.size();
-            bvh.nodes.resize(2 * (size_t)n + 1); bvh.order.resize(n);
-            uint32_t n_nodes = 0;
-            if (rt_bvh_build(scene.prims.data(), scene.centroids.data(), n, bvh.nodes.data(), &n_nodes, bvh.order.data(), &bvh.depth) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
-            bvh.nodes.resize(n_nodes);
-        } else if (!build_bvh(scene, bvh_mode_of(cli.options), bvh, err)) { rt_scene_destroy(dev); return 1; }
-        if (rt_scene_set_bvh(dev, bvh.nodes.data(), (uint32_t)bvh.nodes.size(), bvh.order.data(), (uint32_t)bvh.order.size()) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
-        fprintf(stderr, "BVH constructed in %.2fs (%zu nodes, depth %u)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(), bvh.nodes.size(), bvh.depth);
-    } else if (cli.algorithm == RT_ALGO_GRID) {
+        if (!build_bvh(scene, bvh_mode_of(cli.options), acc.bvh, err)) return 1;
+        acc.have_bvh = true;
+        fprintf(stderr, "BVH constructed in %.2fs (%zu nodes, depth %u)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(), acc.bvh.nodes.size(), acc.bvh.depth);
+    } else if (cli.algorithm == RT_ALGO_GRID && !cli.gpu_build) {
         auto t = std::chrono::steady_clock::now();
-        if (cli.gpu_build) {
-            if (!(cli.grid_size >= 1.0)) { err = "grid size must be at least 1"; rt_scene_destroy(dev); return 1; }
-            if (rt_scene_build_grid(dev, cli.grid_size) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
-        } else {
-            Grid grid;
-            if (!build_grid(scene, cli.grid_size, grid, err)) { rt_scene_destroy(dev); return 1; }
-            if (rt_scene_set_grid(dev, &grid.desc, grid.cell_aabb.data(), grid.cell_offset.data(), grid.prim_list.data()) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
-        }
+        if (!build_grid(scene, cli.grid_size, acc.grid, err)) return 1;
+        acc.have_grid = true;
         fprintf(stderr, "Grid constructed in %.2fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count());
     }
-    rs.init_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    const double host_init = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 
     // cam.render() main.rs:132
     const uint64_t n_pixels = (uint64_t)rc.image_width * rc.image_height;
     std::vector<double> sum(n_pixels * 3);
-    rt_stats st;
-    if (rt_render(dev, &rc, cli.algorithm, 0, cam.samples_per_pixel, cam.max_depth, cli.seed, sum.data(), &st) != RT_OK) { err = rt_last_error(); rt_scene_destroy(dev); return 3; }
-    rt_scene_destroy(dev);
+    rt_stats st; memset(&st, 0, sizeof st);
+    if (cli.gpus <= 1) {
+        double dev_init = 0;
+        const int rcode = render_slice(cli, scene, acc, rc, cam.max_depth, draw_boxes, cli.device, 0, cam.samples_per_pixel, sum.data(), &st, &dev_init, err);
+        if (rcode) return rcode;
+        rs.init_time = host_init + dev_init;
+    } else {
+        // SURVEY 8(e) without a launcher: one worker process per GPU, forked BEFORE anything touches HIP (a forked copy of a
+        // process that has initialised the GPU is not usable), each rendering its own global sample indices of every pixel
+        // into shared memory; the parent adds the partial sums in rank order (fixed association: reproducible for a given N).
+        const uint32_t N = (uint32_t)cli.gpus;
+        struct Slot { int rc; double dev_init; rt_stats st; char err[480]; };
+        const size_t fb_bytes = (size_t)n_pixels * 3 * sizeof(double);
+        const size_t total = (size_t)N * fb_bytes + (size_t)N * sizeof(Slot);
+        void* shm = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (shm == MAP_FAILED) { err = "mmap of the shared framebuffers failed"; return 1; }
+        Slot* slots = (Slot*)((char*)shm + (size_t)N * fb_bytes);
+        fflush(stdout); fflush(stderr);
+        std::vector<pid_t> pids(N, -1);
+        for (uint32_t g = 0; g < N; ++g) {
+            uint32_t sb, scount; spp_range(g, N, cam.samples_per_pixel, sb, scount);
+            pid_t pid = fork();
+            if (pid < 0) { err = "fork failed"; for (uint32_t k = 0; k < g; ++k) { kill(pids[k], SIGKILL); waitpid(pids[k], nullptr, 0); } munmap(shm, total); return 1; }
+            if (pid == 0) {
+                std::string werr; Slot& sl = slots[g];
+                sl.rc = render_slice(cli, scene, acc, rc, cam.max_depth, draw_boxes, cli.device_given ? cli.device : (int)g, sb, scount,
+                                     (double*)((char*)shm + (size_t)g * fb_bytes), &sl.st, &sl.dev_init, werr);
+                snprintf(sl.err, sizeof sl.err, "%s", werr.c_str());
+                fflush(stderr);
+                _exit(sl.rc ? 1 : 0);                 // no static destructors of the parent's copy
+            }
+            pids[g] = pid;
+        }
+        int bad = 0;
+        for (uint32_t g = 0; g < N; ++g) {
+            int status = 0;
+            if (waitpid(pids[g], &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+                if (!bad) err = "worker " + std::to_string(g) + ": " + ((WIFEXITED(status) && slots[g].err[0]) ? std::string(slots[g].err) : std::string("ended abnormally"));
+                bad = 3;
+            }
+        }
+        if (bad) { munmap(shm, total); return bad; }
+        double dev_init = 0;
+        for (uint32_t g = 0; g < N; ++g) {
+            const double* part = (const double*)((const char*)shm + (size_t)g * fb_bytes);
+            if (g == 0) memcpy(sum.data(), part, fb_bytes);
+            else for (size_t i = 0; i < sum.size(); ++i) sum[i] = sum[i] + part[i];
+            const rt_stats& w = slots[g].st;
+            st.primary_rays += w.primary_rays; st.scatter_rays += w.scatter_rays; st.intersection_checks += w.intersection_checks;
+            st.traversal_steps += w.traversal_steps; st.overlapping_aabb += w.overlapping_aabb; st.gridbox_intersection_checks += w.gridbox_intersection_checks;
+            if (w.render_ms > st.render_ms) st.render_ms = w.render_ms;
+            if (slots[g].dev_init > dev_init) dev_init = slots[g].dev_init;
+        }
+        munmap(shm, total);
+        rs.init_time = host_init + dev_init;
+    }
     std::vector<uint8_t> rgb(n_pixels * 3);
     resolve_pixels(sum.data(), n_pixels, cam.samples_per_pixel, rgb.data());
     if (!(cli.binary_ppm ? write_ppm_p6 : write_ppm_p3)(out_filename, rc.image_width, rc.image_height, rgb.data(), err)) return 1;

@@ -22,7 +22,8 @@ struct Cli {                                                                // r
     // additions (the reference hard-codes these in main.rs:72-78; BASELINE configs need them as flags)
     int width = -1, spp = -1, max_depth = -1;
     uint64_t seed = 1;
-    int device = 0;
+    int device = 0; bool device_given = false;
+    int gpus = 1;                       // --gpus N: spp-split over N forked workers, one GPU each; CLI binary only
     int subdivide = 0;                  // synthetic refinement levels for PLY meshes (not a reference feature)
     std::string output_dir = "output";
     bool gpu_build = false;             // --gpu-build: Bvh::new (default SAH mode) / Grid::new on the GPU
@@ -38,6 +39,8 @@ std::string options_to_string(const Cli& cli);
 // get_output_filename rtweekend.rs:175-197
 std::string get_output_filename(const Cli& cli);
 BvhMode bvh_mode_of(const std::vector<AlgorithmOption>& options);
+// raytracer_amd/dist.py spp_range: the global sample indices of one rank
+void spp_range(uint32_t rank, uint32_t world, uint32_t spp, uint32_t& begin, uint32_t& count);
 
 struct RunStats {                       // value/data.rs:6-24, in CSV column order
     double seconds = 0, init_time = 0;

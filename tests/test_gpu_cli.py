@@ -83,3 +83,25 @@ def test_gpu_built_grid_gives_the_same_image(gpu, tmp_path):
     ra, rb = (list(csv.DictReader(open(os.path.join(d, "stats.csv"))))[0] for d in (a, b))
     for k in ("intersection_checks", "traversal_steps", "gridbox_intersection_checks", "scatter_rays"):
         assert ra[k] == rb[k], k
+
+
+def test_cli_gpus_2_equals_gpus_1(gpu, tmp_path):
+    """`raytracer --gpus N` (the host adds --gpus): N forked workers, each rendering its spp_range, partial sums
+    added in rank order by the parent.  Here N = 2 on the box's one GPU (--device 0 makes every worker use it); the image
+    must equal the single-process one (8-bit output: identical up to a rounding tie) and the counters must add up.
+    The CLI binary is started as a child process: a forking host must not have touched HIP itself."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.__file__), "bin", "raytracer")
+    outs = []
+    for n in (1, 2):
+        out = str(tmp_path / f"out{n}")
+        cmd = [exe, "scenes/weekend-final.json", "--width", "128", "--spp", "7", "--seed", "4", "--output-dir", out, "--gpus", str(n), "--device", "0"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        px = np.array(open(os.path.join(out, "weekend-final-bvh.ppm")).read().split()[4:], dtype=int)
+        row = list(csv.DictReader(open(os.path.join(out, "stats.csv"))))[0]
+        outs.append((px, row))
+    (p1, r1), (p2, r2) = outs
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb"):
+        assert r1[k] == r2[k], k
+    assert np.max(np.abs(p1 - p2)) <= 1 and np.mean(p1 != p2) < 1e-3

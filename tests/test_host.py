@@ -146,6 +146,7 @@ def test_cli_output_filenames_follow_the_reference():
     assert _outname("a.json", "-o", "bvh-naive", "-o", "bvh-sah-plane")[0] == -2          # check_valid_options rtweekend.rs:150-160
     assert _outname("a.json", "--algorithm", "octree")[0] == -1
     assert _outname("a.json", "--bogus")[0] == -1
+    assert _outname("a.json", "--gpus", "8")[0] == 0 and _outname("a.json", "--gpus", "0")[0] == -1 and _outname("a.json", "--gpus=65")[0] == -1
 
 
 def test_camera_presets_follow_main_rs():
