@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--spp-per-gpu", type=int, default=128)
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_res3", "dragon_res4", "weekend-final", "weekend-mixed"])
+    ap.add_argument("--algorithm", default="bvh", choices=["bvh", "grid", "naive"], help="profiling of the other walks; the headline is bvh")
+    ap.add_argument("--grid-size", type=float, default=5.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsing N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU (needs --backend gloo)")
@@ -113,7 +115,7 @@ def main():
 
     t0 = time.time()
     w, cam_name, label = load_scene(a.scene)
-    w.algorithm, w.bvh_mode = "bvh", "sah-position"
+    w.algorithm, w.bvh_mode, w.grid_size = a.algorithm, "sah-position", a.grid_size
     w.init()
     w.upload()
     init_s = time.time() - t0
@@ -168,7 +170,7 @@ def main():
         seg, nbox, nprim = agg["ray_segments"], agg["box_tests"], agg["prim_tests"]
         launches = max(agg["extend_launches"], 1)
         ext_s = agg["extend_ms"] / 1e3
-        pair_b, prim_b = w.bvh_layout()                         # what the kernel's layout for this scene really reads
+        pair_b, prim_b = w.bvh_layout() if a.algorithm == "bvh" else (0, 80)   # what the kernel's layout for this scene really reads
         counts = {"segments": seg, "box_tests": nbox, "prim_tests": nprim, "launches": launches, "extend_s": ext_s,
                   "pair_bytes": pair_b, "prim_bytes": prim_b}
         out = {
@@ -176,9 +178,9 @@ def main():
             "value": total_rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if "synthetic" in label else "real mesh",
-            "config": {"workload": f"{label}; --algorithm bvh (SAH position); {W}x{H}; {a.spp_per_gpu} spp per GPU "
+            "config": {"workload": f"{label}; --algorithm {'bvh (SAH position)' if a.algorithm == 'bvh' else a.algorithm + (f' size={a.grid_size:g}' if a.algorithm == 'grid' else '')}; {W}x{H}; {a.spp_per_gpu} spp per GPU "
                                    f"({a.spp_per_gpu * world} spp total, spp-split); max_depth {a.max_depth}; camera preset dragon/0",
-                       "primitives": len(w), "bvh_nodes": w.bvh.n_nodes, "bvh_depth": w.bvh.depth,
+                       "primitives": len(w), "bvh_nodes": w.bvh.n_nodes if w.bvh else None, "bvh_depth": w.bvh.depth if w.bvh else None,
                        "parallelism": f"spp-split x{world}, replicated scene, one RCCL reduce of the f64 framebuffer per step ({world} ranks)" if world > 1 else "single GPU",
                        "init_seconds_excluded": round(init_s, 2)},
             "rays_per_step": total_rays / a.steps,
@@ -238,7 +240,8 @@ def pmc_passes(a):
     tmp = tempfile.mkdtemp(prefix="rt_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     keep = os.path.join(ROOT, "gpurun_out", "bench_pmc")
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc",
-             "--width", str(a.width), "--spp-per-gpu", str(a.spp_per_gpu), "--max-depth", str(a.max_depth), "--scene", a.scene]
+             "--width", str(a.width), "--spp-per-gpu", str(a.spp_per_gpu), "--max-depth", str(a.max_depth), "--scene", a.scene,
+             "--algorithm", a.algorithm, "--grid-size", str(a.grid_size)]
     res = {"counters": {}, "dispatches": 0, "child": None, "seconds": {}, "kernel_ns": 0.0,
            "source": "rocprofv3 --pmc passes of this run's own workload (one step per pass, separate child processes)"}
     env = dict(os.environ); env["TMPDIR"] = "/tmp"
@@ -265,7 +268,7 @@ def pmc_passes(a):
             res["child"] = json.loads(lines[-1])["pmc_child"]
         seen = set()
         for r in csv.DictReader(open(f[0])):
-            if "k_extend_bvh2" not in r["Kernel_Name"]:
+            if "k_extend" not in r["Kernel_Name"]:
                 continue
             res["counters"][r["Counter_Name"]] = res["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             if name == "sq" and r["Dispatch_Id"] not in seen:
@@ -286,7 +289,7 @@ def roofline(c, pmc):
     alg_bytes = 60.0 * seg + 64.0 * nbox + 72.0 * nprim          # (48 in + 12 out) + 64 per box test + 72 per triangle test
     layout_bytes = 60.0 * seg + 0.5 * pair_b * nbox + prim_b * nprim
     lane_acc = ((pair_b / 16.0) * 0.5 * nbox + (prim_b / 16.0) * nprim + 6.0 * seg) / ext_s / (256 * 2.4e9) if ext_s > 0 else 0.0
-    r = {"kernel": "k_extend_bvh2", "avg_launch_ms": ext_s * 1e3 / launches, "launches": launches,
+    r = {"kernel": "k_extend_bvh2" if pair_b else "k_extend_grid / k_extend_naive", "avg_launch_ms": ext_s * 1e3 / launches, "launches": launches,
          # the contract's byte model, as plain fields: it prices every box test at 64 B from HBM, while the tree sits in the
          # Infinity Cache / L2 and the compact layout requests half of it, so this rate can exceed the HBM peak and is no bound
          "algorithmic_bytes_per_launch": alg_bytes / launches, "algorithmic_GBps": alg_bytes / ext_s / 1e9 if ext_s > 0 else 0.0,

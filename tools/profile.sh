@@ -3,9 +3,10 @@
 # usage: tools/profile.sh <tag> [bench args...]; results under gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:-"--steps 1 --warmup 0 --spp-per-gpu 8 --no-cpu-baseline"}
+ARGS=${@:-"--steps 1 --warmup 0 --spp-per-gpu 8 --no-cpu-baseline --no-pmc"}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
+echo "$ARGS" > $OUT/args.txt
 export TMPDIR=/tmp
 run() { # name, rocprof flags...
   local name=$1; shift
