@@ -45,7 +45,8 @@ RT_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
         if (r) { k0 += W0; k1 += W1; }
         const uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];      // one v_mad_u64_u32 each instead of mul_hi + mul_lo
         const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-        uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+        // three-input xor in one instruction (gfx950 v_bitop3_b32, truth table 0x96); the compiler emits two v_xor_b32 otherwise
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32(h1, c[1], k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, c[3], k1, 0x96);
         c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
     }
 }
