@@ -417,3 +417,45 @@ def test_extend_blocks_raised_after_set_bvh_stays_inside_the_stack(gpu, monkeypa
     monkeypatch.setenv("RT_EXTEND_BLOCKS", "2048"); rt.init(0)
     assert np.array_equal(a, b) and sa["intersection_checks"] == sb["intersection_checks"] and sa["scatter_rays"] == sb["scatter_rays"]
     w.close()
+
+
+def _edge_rays(w, n, seed):
+    """Rays built to reach the corners of the reference's arithmetic: direction components that are +0 / -0 (1/d = +-inf, and
+    0 * inf = NaN wherever the origin lies ON a box plane, aabb.rs:34-51), origins exactly on vertices, box planes and sphere
+    centres, axis-aligned and all-zero directions, denormal and huge components, and a few non-finite origins."""
+    rng = np.random.default_rng(seed)
+    p = w.prims()
+    pts = np.concatenate([p["v"][:, 0:3], p["v"][p["type"] == 1][:, 3:6], p["v"][p["type"] == 1][:, 6:9]])
+    if w.bvh is not None:
+        nd = w.bvh.nodes()
+        pts = np.concatenate([pts, nd["min"], nd["max"]])
+    o = pts[rng.integers(len(pts), size=n)].copy()
+    # mix coordinates of different points so that an origin shares ONE plane with a box and is off the others
+    mix = rng.random((n, 3)) < 0.5
+    o[mix] = pts[rng.integers(len(pts), size=n)][mix]
+    o += rng.choice([0.0, 0.0, 0.0, 1e-12, -3.0, 7.0], size=(n, 1)) * rng.normal(size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    z = rng.random((n, 3)) < 0.35
+    d[z] = rng.choice([0.0, -0.0], size=int(z.sum()))
+    k = n // 16
+    d[:k] *= 1e-310                                             # denormal components: 1/d overflows to inf
+    d[k:2 * k] *= 1e200
+    o[2 * k:2 * k + 8, 0] = [np.inf, -np.inf, np.nan, 1e308, -1e308, 0.0, -0.0, 5e-324]
+    return o, d
+
+
+@pytest.mark.parametrize("scene,algorithm,grid_size", [("triangle_materials", "bvh", None), ("triangle_materials", "naive", None),
+                                                       ("triangle_materials", "grid", 5.0), ("weekend-5-80-15", "bvh", None),
+                                                       ("weekend-5-80-15", "grid", 25.0), ("mixed", "bvh", None), ("mixed", "grid", 5.0),
+                                                       ("dragon_res4", "bvh", None), ("dragon_res4", "grid", 5.0), ("dragon_res4", "grid", 1.0)])
+def test_degenerate_rays_bit_exact(gpu, scene, algorithm, grid_size):
+    """NaN / inf / signed-zero behaviour of the slab, sphere and triangle tests and of the grid's saturating casts is the
+    reference's, comparison by comparison: hit flags, primitives, rec.t / rec.p bits and all counters equal the oracle's."""
+    w = weekend_mixed() if scene == "mixed" else load_world(scene)
+    osc = setup_pair(w, algorithm, "sah-position", grid_size or 25.0, oracle_own_build=scene != "dragon_res4")
+    w.upload()
+    o, d = _edge_rays(w, 6000 if algorithm != "naive" else 2000, 31)
+    with np.errstate(all="ignore"):
+        assert_trace_equal(w.hit(o, d), osc.trace(algorithm, o, d), f"{scene}/{algorithm} degenerate rays, tmax inf")
+        assert_trace_equal(w.hit(o, d, 0.001, 50.0), osc.trace(algorithm, o, d, 0.001, 50.0), f"{scene}/{algorithm} degenerate rays, tmax 50")
+    w.close()
