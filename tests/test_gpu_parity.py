@@ -459,3 +459,47 @@ def test_degenerate_rays_bit_exact(gpu, scene, algorithm, grid_size):
         assert_trace_equal(w.hit(o, d), osc.trace(algorithm, o, d), f"{scene}/{algorithm} degenerate rays, tmax inf")
         assert_trace_equal(w.hit(o, d, 0.001, 50.0), osc.trace(algorithm, o, d, 0.001, 50.0), f"{scene}/{algorithm} degenerate rays, tmax 50")
     w.close()
+
+
+def _random_scene(seed, n=60):
+    """A scene the reference's loaders could produce but none of the committed files does: overlapping spheres and triangles,
+    zero-radius spheres, zero-area and sliver triangles, coincident primitives, metal fuzz 0 / 1, refraction indices around 1."""
+    from raytracer_amd import HittableList
+    from raytracer_amd.host import _MAT_DT, _PRIM_DT
+    rng = np.random.default_rng(seed)
+    prims = np.zeros(n, _PRIM_DT)
+    prims["type"] = rng.integers(0, 2, size=n)
+    c = rng.uniform(-4, 4, size=(n, 3)) + np.array([0.0, 0.0, -6.0])
+    for i in range(n):
+        if prims["type"][i] == 0:
+            prims["v"][i, :3] = c[i]; prims["v"][i, 3] = rng.choice([0.0, 0.05, 0.5, 1.5, 3.0])
+        else:
+            tri = c[i] + rng.normal(scale=rng.choice([1e-9, 0.3, 2.0]), size=(3, 3))
+            if rng.random() < 0.1: tri[2] = tri[1]                       # zero area
+            prims["v"][i] = tri.ravel()
+    prims[n - 1] = prims[0]; prims[n - 2] = prims[1]                     # coincident primitives: order decides
+    mats = np.zeros(8, _MAT_DT)
+    mats["type"] = [0, 0, 1, 1, 1, 2, 2, 2]
+    mats["albedo"] = rng.uniform(0.1, 1.0, size=(8, 3))
+    mats["param"] = [0, 0, 0.0, 1.0, 0.3, 1.5, 1.0, 0.7]
+    prims["material"] = rng.integers(0, 8, size=n)
+    v = prims["v"]
+    cent = np.where((prims["type"] == 0)[:, None], v[:, :3], ((v[:, 0:3] + v[:, 3:6]) + v[:, 6:9]) / 3.0)
+    return HittableList.from_arrays(prims, cent, mats, filename="scenes/random.json")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("algorithm,grid_size", [("bvh", None), ("grid", 5.0), ("naive", None)])
+def test_random_scenes_render_matches_oracle(gpu, seed, algorithm, grid_size):
+    w = _random_scene(seed)
+    osc = setup_pair(w, algorithm, "sah-position", grid_size or 25.0)
+    w.upload()
+    cam = Camera(w.filename, image_width=64, samples_per_pixel=6, max_depth=12)
+    img, st = cam.render(w, seed=seed)
+    ref, cst = osc.render(O.camera_from_rt(cam.c), algorithm, 0, 6, 12, seed=seed, nthreads=8)
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb", "gridbox_intersection_checks"):
+        assert st[k] == cst[k], f"seed {seed} {algorithm}: counter {k}: gpu {st[k]} oracle {cst[k]}"
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(img), fin)
+    assert np.max(np.abs(img[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300), initial=0.0) <= RADIANCE_RTOL
+    w.close()
