@@ -288,3 +288,11 @@ def test_parallel_ply_parse_time_on_a_full_size_mesh(tmp_path, monkeypatch):
     assert out[True][0] == out[False][0] and len(out[True][0]) == len(faces) * 80
     assert np.array_equal(np.frombuffer(out[True][0], dtype=w.prims().dtype)["v"], w.prims()["v"])       # and it is the mesh that was written
     print(f"\nASCII PLY, {len(faces)} faces, {os.path.getsize(path) >> 20} MiB: token parser {out[False][1]:.2f} s, threads {out[True][1]:.2f} s")
+
+
+def test_in_process_run_refuses_gpus_flag():
+    """`--gpus N` forks workers before the first HIP call, which only the CLI binary can guarantee: rth_run (in-process) says so."""
+    import raytracer_amd as rt
+    from raytracer_amd.host import RtError
+    with pytest.raises(RtError, match="raytracer binary"):
+        rt.run(["scenes/simple_fuzzy_metal.json", "--gpus", "2"])
