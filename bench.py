@@ -253,7 +253,7 @@ def pmc_passes(a):
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
             try:
-                log, _ = p.communicate(timeout=240)
+                log, _ = p.communicate(timeout=120)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL); p.wait()
                 res["error"] = f"pass {name}: timed out"; break
