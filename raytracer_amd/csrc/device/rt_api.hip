@@ -700,16 +700,9 @@ int rt_trace(rt_scene* sc, int algorithm, const double* orig, const double* dir,
     if (rc) return rc;
     Workspace& w = sc->ws;
     hipStream_t st = g_stream;
-    struct Staging {                                         // freed on every exit path
-        double *o = nullptr, *d = nullptr, *t = nullptr; uint8_t* h = nullptr;
-        ~Staging() { if (o) (void)hipFree(o); if (d) (void)hipFree(d); if (t) (void)hipFree(t); if (h) (void)hipFree(h); }
-    } sg;
-    const uint64_t cmax = n < chunk ? (n ? n : 1) : chunk;
-    HIPCHECK(hipMalloc(&sg.o, cmax * 3 * sizeof(double)));
-    HIPCHECK(hipMalloc(&sg.d, cmax * 3 * sizeof(double)));
-    HIPCHECK(hipMalloc(&sg.t, cmax * sizeof(double)));
-    HIPCHECK(hipMalloc(&sg.h, cmax));
-    double *d_o = sg.o, *d_d = sg.d, *d_t = sg.t; uint8_t* d_h = sg.h;
+    // staging lives in the parts of the workspace a trace does not use: the second ray queue (interleaved origins and
+    // directions of a chunk), the accept-time t array (rec.t) and the second id array (the hit byte)
+    double *d_o = w.qbuf[1], *d_d = w.qbuf[1] + 3 * w.cap, *d_t = w.hit_tn; uint8_t* d_h = (uint8_t*)w.qid[1];
     HIPCHECK(hipMemsetAsync(w.stats, 0, ST_N * sizeof(unsigned long long), st));
     int ret = RT_OK;
     for (uint64_t off = 0; off < n && ret == RT_OK; off += chunk) {
