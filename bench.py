@@ -195,6 +195,8 @@ def main():
             # free this process's HBM (the workspace alone is ~200 GB) before the profiled children allocate theirs
             w.close(); del fb; torch.cuda.empty_cache()
             pmc = pmc_passes(a)
+        if pmc is None and world > 1:
+            pmc = committed_pmc(out["config"]["workload"], world, a)
         out["roofline"] = roofline(counts, pmc)
         if world == 1 and not a.no_cpu_baseline:
             print("[bench] CPU baseline (oracle, 1 core, then all cores) ...", file=sys.stderr, flush=True)
@@ -281,6 +283,24 @@ def pmc_passes(a):
             pass
     shutil.rmtree(tmp, ignore_errors=True)
     return res
+
+
+def committed_pmc(workload, world, a):
+    """N > 1: rank 0 renders global samples [0, spp_per_gpu) of every pixel - exactly the paths of the N = 1 run, so its extend
+    kernel does the same work per ray segment.  The counters of the committed N = 1 line (profiles/round2_bench.json, same
+    scene / image / spp per GPU / depth) are used with this run's own times, and the line says so."""
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "round2_bench.json")))
+        same = ref["config"]["workload"].split(";")[:3] == workload.split(";")[:3] and f"{a.spp_per_gpu} spp per GPU" in ref["config"]["workload"] \
+            and f"max_depth {a.max_depth}" in ref["config"]["workload"]
+        p = ref["roofline"]["pmc"]
+        if not same or "counters" not in p:
+            return None
+        return {"counters": p["counters"], "child": {"segments": p["segments_profiled"]}, "dispatches": p["dispatches_profiled"], "seconds": {}, "kernel_ns": 0.0,
+                "source": f"counters of the committed N = 1 run of the same per-GPU workload (profiles/round2_bench.json), scaled by ray segments to "
+                          f"rank 0's timed steps of this {world}-GPU run: rank 0 traces the same paths"}
+    except Exception:
+        return None
 
 
 def roofline(c, pmc):

@@ -79,3 +79,29 @@ def test_bench_gpus_flag_starts_that_many_ranks(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
         bench.main()
+
+
+def test_multi_gpu_bench_line_reuses_the_committed_single_gpu_counters():
+    """N > 1 cannot run the profiler passes; rank 0 traces the paths of the N = 1 run, so bench.py prices its own times with the
+    committed N = 1 counters when the per-GPU workload is the same, and with nothing otherwise."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ref = json.load(open(os.path.join(root, "profiles", "round2_bench.json")))
+
+    class A:
+        spp_per_gpu, max_depth = 128, 50
+    wl8 = ref["config"]["workload"].replace("(128 spp total", "(1024 spp total")
+    p = bench.committed_pmc(wl8, 8, A)
+    assert p and "committed N = 1 run" in p["source"] and p["child"]["segments"] == ref["roofline"]["pmc"]["segments_profiled"]
+    r = ref["roofline"]
+    seg = p["child"]["segments"]
+    c = {"segments": seg, "box_tests": int(r["box_tests_per_segment"] * seg), "prim_tests": int(r["prim_tests_per_segment"] * seg),
+         "launches": 45, "extend_s": r["avg_launch_ms"] * 45 / 1e3, "pair_bytes": 64, "prim_bytes": 48}
+    rr = bench.roofline(c, p)
+    assert rr["bound"] == "valu" and abs(rr["frac"] - r["frac"]) < 0.01 and 0 < rr["hbm"]["frac"] < 1
+    A.spp_per_gpu = 64
+    assert bench.committed_pmc(wl8, 8, A) is None
+    assert bench.roofline(c, None)["bound"] == "l1_lane_access"
