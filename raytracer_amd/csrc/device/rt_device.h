@@ -367,6 +367,21 @@ RT_DEV bool slab_fast_d(const double* dmn, const double* dmx, V3 inv, double& tm
     tmin = vmax_f64(tmin, vmin_f64(t0, t1)); tmax = vmin_f64(tmax, vmax_f64(t0, t1));
     return !(tmax < tmin);
 }
+// slab_fast_d for the two boxes of a sibling pair with the two dependency chains interleaved: consecutive v_min/v_max_f64
+// then never depend on each other, so the hazard wait states (s_nop) the compiler puts between dependent ones disappear.
+// Same operations on the same operands as two slab_fast_d calls.
+RT_DEV void slab_fast_d2(const double* Lmn, const double* Lmx, const double* Rmn, const double* Rmx, V3 inv,
+                         double& ltmin, double& ltmax, double& rtmin, double& rtmax, bool& lh, bool& rh) {
+    const double iv[3] = {inv.x, inv.y, inv.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double l0 = Lmn[a] * iv[a], l1 = Lmx[a] * iv[a], r0 = Rmn[a] * iv[a], r1 = Rmx[a] * iv[a];
+        const double ln = vmin_f64(l0, l1), rn = vmin_f64(r0, r1), lf = vmax_f64(l0, l1), rf = vmax_f64(r0, r1);
+        ltmin = vmax_f64(ltmin, ln); rtmin = vmax_f64(rtmin, rn);
+        ltmax = vmin_f64(ltmax, lf); rtmax = vmin_f64(rtmax, rf);
+    }
+    lh = !(ltmax < ltmin); rh = !(rtmax < rtmin);
+}
 RT_DEV bool is_finite(double x) { return fabs(x) < __builtin_huge_val(); }     // false for inf and NaN
 RT_DEV bool ray_is_regular(V3 o, V3 inv) {
     return is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv.x) && is_finite(inv.y) && is_finite(inv.z);

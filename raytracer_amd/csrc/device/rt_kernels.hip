@@ -428,7 +428,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 }
                 double ld = tmin0, lx = tmax, rd = tmin0, rx = tmax;
                 bool lh, rh;
-                if (all_regular) { lh = slab_fast_d(dLmn, dLmx, inv, ld, lx); rh = slab_fast_d(dRmn, dRmx, inv, rd, rx); }
+                if (all_regular) slab_fast_d2(dLmn, dLmx, dRmn, dRmx, inv, ld, lx, rd, rx, lh, rh);
                 else { lh = slab_d(dLmn, dLmx, inv, ld, lx); rh = slab_d(dRmn, dRmx, inv, rd, rx); }
                 const bool both = lh && rh;
                 const bool go_right = rh && (!lh || ld >= rd); // bvh.rs:210-211 (tie -> right is `close`), :226-227; as lane-mask logic
