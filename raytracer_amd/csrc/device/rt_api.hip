@@ -60,6 +60,7 @@ int g_extend_variant = 2;             // 1 = one ray per thread per pass, 2 = pe
 int g_lg_samples = 7;                 // log2 of the samples of one pixel per generate wave; 7 = choose per batch (RT_LG_SAMPLES overrides)
 bool g_tri_pre = true;                // RT_TRI_PRE=0: naive / grid walks recompute the triangle normal per test (A/B)
 bool g_bounce_log = false;            // RT_BOUNCE_LOG=1: per-bounce kernel times on stderr while profiling is on
+bool g_cell_tri = true;               // RT_CELL_TRI=0: the grid walk reads list entry -> plane record instead of the per-position records (A/B)
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 
 struct EventPool {
@@ -126,6 +127,7 @@ struct rt_scene {
     // grid
     bool have_grid = false; DGrid grid{}; rt_grid_desc grid_desc{}; uint64_t grid_list_len = 0;
     double* d_cell_aabb = nullptr; uint64_t* d_cell_offset = nullptr; uint32_t* d_prim_list = nullptr;
+    DCellTri* d_cell_tri = nullptr;    // all-triangle scenes: plane record + index per list position (k_cell_tri)
     Workspace ws;
 };
 
@@ -418,6 +420,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_LG_SAMPLES")) { int v = atoi(s); if (v >= 0 && v <= 7) g_lg_samples = v; }
     if (const char* s = getenv("RT_TRI_PRE")) g_tri_pre = atoi(s) != 0;
     if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
+    if (const char* s = getenv("RT_CELL_TRI")) g_cell_tri = atoi(s) != 0;
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_STREAM_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_stream_blocks = (uint32_t)v & ~7u; }
     if (const char* s = getenv("RT_ACC_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 1 && v <= 1048576) g_acc_blocks = (uint32_t)v; }
@@ -487,6 +490,7 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
     if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
+    if (sc->d_cell_tri) (void)hipFree(sc->d_cell_tri);
     sc->ws.release();
     delete sc;
 }
@@ -640,6 +644,15 @@ static void install_grid(rt_scene* sc, const rt_grid_desc& gd, uint64_t list_len
     double tz = gd.total_size[2];                                   /* grid.rs:152: `self.total_size.z() as u32` */
     g.max_depth = !(tz > 0.0) ? 0u : (tz >= 4294967295.0 ? 0xffffffffu : (uint32_t)tz);
     g.cell_aabb = sc->d_cell_aabb; g.cell_offset = sc->d_cell_offset; g.prim_list = sc->d_prim_list;
+    if (sc->d_cell_tri) { (void)hipFree(sc->d_cell_tri); sc->d_cell_tri = nullptr; }
+    // optional (the walk falls back to the per-triangle plane records): 48 B per list position, at most 8 GiB; only where cells
+    // hold many triangles (res4 dragon at 900x506x50: size 25 1 679 -> 1 469 ms, size 5 349 -> 322 ms, size 2 equal, size 1 +4 %)
+    if (g_cell_tri && sc->d_tri_pre && list_len && list_len * 10ull >= gd.n_cells && list_len <= (8ull << 30) / sizeof(DCellTri)
+        && hipMalloc(&sc->d_cell_tri, list_len * sizeof(DCellTri)) == hipSuccess) {
+        hipLaunchKernelGGL(k_cell_tri, dim3((unsigned)((list_len + 255) / 256)), dim3(256), 0, g_stream, sc->d_prim_list, sc->d_tri_pre, list_len, sc->d_cell_tri);
+        if (hipStreamSynchronize(g_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sc->d_cell_tri); sc->d_cell_tri = nullptr; }
+    } else (void)hipGetLastError();
+    g.cell_tri = sc->d_cell_tri;
     sc->grid_desc = gd; sc->grid_list_len = list_len;
     sc->have_grid = true;
 }

@@ -301,6 +301,34 @@ RT_DEV bool hit_triangle_pre(const DPrim* __restrict__ prims, const DTriPre* __r
     return true;
 }
 
+// The same test for the grid walk, with the triangle's plane record stored IN the cell's list (one 48-byte entry per list
+// position: the plane and the primitive index): a list entry is then one sequential load instead of the chain
+// list entry -> plane record, and the vertices are fetched only when the n.dir test passes.
+struct __align__(16) DCellTri { double n[3]; double dd; uint32_t pi; uint32_t pad[3]; };
+RT_DEV bool hit_triangle_cell(const DPrim* __restrict__ prims, const DCellTri& q, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
+    const V3 n = v3(q.n[0], q.n[1], q.n[2]);
+    double n_dot_dir = dot(n, d);
+    if (!(tmin < n_dot_dir && n_dot_dir < tmax)) return false;
+    double t = -(dot(n, o) + q.dd) / n_dot_dir;
+    rec.t = t;
+    if (t < 0.0) return false;
+    rec.tp = t;
+    const DPrim tr = prims[q.pi];
+    V3 v0 = v3(tr.v[0], tr.v[1], tr.v[2]), v1 = v3(tr.v[3], tr.v[4], tr.v[5]), v2 = v3(tr.v[6], tr.v[7], tr.v[8]);
+    V3 p = o + (t * d);
+    V3 v0v1 = v1 - v0;
+    V3 v0p = p - v0;
+    if (dot(n, cross(v0v1, v0p)) <= 0.0) return false;
+    V3 v1v2 = v2 - v1;
+    V3 v1p = p - v1;
+    if (dot(n, cross(v1v2, v1p)) <= 0.0) return false;
+    V3 v2v0 = v0 - v2;
+    V3 v2p = p - v2;
+    if (dot(n, cross(v2v0, v2p)) <= 0.0) return false;
+    rec.prim = (int32_t)q.pi; rec.tn = t;
+    return true;
+}
+
 RT_DEV bool hit_prim(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
     return (p.tm >> 31) ? hit_triangle(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
 }

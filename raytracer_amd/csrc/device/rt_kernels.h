@@ -27,6 +27,7 @@ struct DCamera { uint32_t W, H; V3 center, pixel00, du, dv, ddu, ddv; double def
 struct DGrid {
     V3 box_size, origin, end, total_size; uint64_t n_cells; uint32_t max_depth;
     const double* cell_aabb; const uint64_t* cell_offset; const uint32_t* prim_list;
+    const DCellTri* cell_tri;      // nullable: per list position, the triangle's plane record and index (all-triangle scenes)
 };
 
 enum { ST_SCATTER = 0, ST_BOX, ST_PRIM, ST_STEPS, ST_OVERLAP, ST_GRIDBOX, ST_SEGMENTS, ST_N };
@@ -47,6 +48,7 @@ template <int NODES, int PRIMS, bool TRACE>
 __global__ void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
 __global__ void k_tri_pre(const DPrim* prims, uint32_t n, DTriPre* pre);
+__global__ void k_cell_tri(const uint32_t* prim_list, const DTriPre* pre, uint64_t n, DCellTri* out);
 __global__ void k_extend_naive(const DPrim* prims, const DTriPre* pre, uint32_t n_prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                                double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 template <bool DRAW>

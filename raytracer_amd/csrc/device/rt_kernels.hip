@@ -547,6 +547,16 @@ __global__ void k_tri_pre(const DPrim* __restrict__ prims, uint32_t n, DTriPre* 
     pre[i] = q;
 }
 
+// per list position of the grid: plane record + index (DCellTri), gathered once when the grid is installed
+__global__ void k_cell_tri(const uint32_t* __restrict__ prim_list, const DTriPre* __restrict__ pre, uint64_t n, DCellTri* __restrict__ out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t pi = prim_list[k];
+    const DTriPre q = pre[pi];
+    DCellTri c; c.n[0] = q.n[0]; c.n[1] = q.n[1]; c.n[2] = q.n[2]; c.dd = q.dd; c.pi = pi; c.pad[0] = c.pad[1] = c.pad[2] = 0;
+    out[k] = c;
+}
+
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_naive(const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre, uint32_t n_prims,
                                                            RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                            double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
@@ -668,7 +678,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
             bool any = false;
             double closest = tmax0;
             uint64_t lo = g.cell_offset[cell], hi = g.cell_offset[cell + 1];
-            if (pre) {
+            if (g.cell_tri) {
+                for (uint64_t k = lo; k < hi; ++k) {
+                    ++c_prim;
+                    const DCellTri ct = g.cell_tri[k];
+                    if (hit_triangle_cell(prims, ct, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                }
+            } else if (pre) {
                 for (uint64_t k = lo; k < hi; ++k) {
                     ++c_prim;
                     uint32_t pi = g.prim_list[k];
