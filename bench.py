@@ -334,7 +334,11 @@ def roofline(c, pmc):
                   "valu": {"lane_utilisation": lane_util, "issue_frac": issued / ext_s / VALU_PEAK_LANE_OPS,
                            "valu_wave_insts_per_segment": k["SQ_INSTS_VALU"] / ch["segments"],
                            "wave_wait_fraction": k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
-                           "clock_GHz_profiled": (k["GRBM_GUI_ACTIVE"] / 8.0 / pmc["kernel_ns"]) if k.get("GRBM_GUI_ACTIVE") and pmc.get("kernel_ns") else None}})
+                           "clock_GHz_profiled": (k["GRBM_GUI_ACTIVE"] / 8.0 / pmc["kernel_ns"]) if k.get("GRBM_GUI_ACTIVE") and pmc.get("kernel_ns") else None,
+                           # occupancy: wave lifetimes (SQ_WAVE_CYCLES counts quad-cycles) over the kernel's cycles, per SIMD (1024 of them);
+                           # the kernel's 126 VGPRs allow 4
+                           "mean_resident_waves_per_simd": (k["SQ_WAVE_CYCLES"] * 4.0 / (k["GRBM_GUI_ACTIVE"] / 8.0) / 1024.0)
+                           if k.get("GRBM_GUI_ACTIVE") and k.get("SQ_WAVE_CYCLES") else None}})
         if k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
             cal, cal_src = fetch_calibration()
             fetch_b = k["FETCH_SIZE"] * 1024.0 * cal * scale; write_b = k["WRITE_SIZE"] * 1024.0 * scale      # counter unit: KiB
