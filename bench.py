@@ -111,7 +111,7 @@ def main():
     import raytracer_amd as rt
     from raytracer_amd import Camera
     rt.init(local_rank)
-    rt.set_profiling(True)
+    rt.set_profiling(a.pmc_child)                             # the timed steps run the path and nothing else (no event records)
 
     t0 = time.time()
     w, cam_name, label = load_scene(a.scene)
@@ -159,6 +159,18 @@ def main():
                 agg[k] += st[k]
     fence()
     dt = time.perf_counter() - t1
+    # one more step with per-kernel HIP events on the library's launch stream (rt_set_profiling): the kernel times the roofline
+    # divides by.  Same seed, same paths: its counters equal one timed step's.
+    if a.pmc_child:                                           # the counter passes: exactly one step under the profiler
+        prof, dt_prof = st, dt
+    else:
+        rt.set_profiling(True)
+        fence()
+        t2 = time.perf_counter()
+        prof = step()
+        fence()
+        dt_prof = time.perf_counter() - t2
+        rt.set_profiling(False)
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     rays = torch.tensor([float(agg["primary_rays"] + agg["scatter_rays"])], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -167,9 +179,9 @@ def main():
     dt = float(tt.item()); total_rays = float(rays.item())
 
     if rank == 0:
-        seg, nbox, nprim = agg["ray_segments"], agg["box_tests"], agg["prim_tests"]
-        launches = max(agg["extend_launches"], 1)
-        ext_s = agg["extend_ms"] / 1e3
+        seg, nbox, nprim = prof["ray_segments"], prof["box_tests"], prof["prim_tests"]
+        launches = max(prof["extend_launches"], 1)
+        ext_s = prof["extend_ms"] / 1e3
         pair_b, prim_b = w.bvh_layout() if a.algorithm == "bvh" else (0, 80)   # what the kernel's layout for this scene really reads
         counts = {"segments": seg, "box_tests": nbox, "prim_tests": nprim, "launches": launches, "extend_s": ext_s,
                   "pair_bytes": pair_b, "prim_bytes": prim_b}
@@ -184,7 +196,10 @@ def main():
                        "parallelism": f"spp-split x{world}, replicated scene, one RCCL reduce of the f64 framebuffer per step ({world} ranks)" if world > 1 else "single GPU",
                        "init_seconds_excluded": round(init_s, 2)},
             "rays_per_step": total_rays / a.steps,
-            "kernel_ms_per_step": {k: agg[k] / a.steps for k in ("generate_ms", "extend_ms", "shade_ms", "resolve_ms")},
+            "kernel_ms_per_step": {k: prof[k] for k in ("generate_ms", "extend_ms", "shade_ms", "resolve_ms")},
+            "profiled_step": {"ms": dt_prof * 1e3, "note": "one extra step after the timed ones with per-kernel HIP events on; "
+                              "kernel_ms_per_step and the roofline's launch times come from it, value / ms_per_step from the un-profiled steps"},
+            "source_hash": source_hash(),
         }
         if a.pmc_child:                                         # the profiled re-run only reports what the parent normalises by
             out["pmc_child"] = counts
@@ -285,20 +300,35 @@ def pmc_passes(a):
     return res
 
 
+def source_hash():
+    """sha1 over the device sources the kernels are built from: a committed N = 1 line is only reused (committed_pmc) for the
+    kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "raytracer_amd", "csrc", "device", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+COMMITTED_LINE = os.path.join("profiles", "round3_bench.json")
+
+
 def committed_pmc(workload, world, a):
     """N > 1: rank 0 renders global samples [0, spp_per_gpu) of every pixel - exactly the paths of the N = 1 run, so its extend
-    kernel does the same work per ray segment.  The counters of the committed N = 1 line (profiles/round2_bench.json, same
-    scene / image / spp per GPU / depth) are used with this run's own times, and the line says so."""
+    kernel does the same work per ray segment.  The counters of the committed N = 1 line (same scene / image / spp per GPU /
+    depth, and the same device sources by hash) are used with this run's own times; the roofline then says measured = false.
+    A line measured on other kernels is not used: the counter-free lane-access fraction is reported instead."""
     try:
-        ref = json.load(open(os.path.join(ROOT, "profiles", "round2_bench.json")))
+        ref = json.load(open(os.path.join(ROOT, COMMITTED_LINE)))
         same = ref["config"]["workload"].split(";")[:3] == workload.split(";")[:3] and f"{a.spp_per_gpu} spp per GPU" in ref["config"]["workload"] \
-            and f"max_depth {a.max_depth}" in ref["config"]["workload"]
+            and f"max_depth {a.max_depth}" in ref["config"]["workload"] and ref.get("source_hash") == source_hash()
         p = ref["roofline"]["pmc"]
         if not same or "counters" not in p:
             return None
         return {"counters": p["counters"], "child": {"segments": p["segments_profiled"]}, "dispatches": p["dispatches_profiled"], "seconds": {}, "kernel_ns": 0.0,
-                "source": f"counters of the committed N = 1 run of the same per-GPU workload (profiles/round2_bench.json), scaled by ray segments to "
-                          f"rank 0's timed steps of this {world}-GPU run: rank 0 traces the same paths"}
+                "committed": True,
+                "source": f"counters of the committed N = 1 run of the same per-GPU workload and the same device sources ({COMMITTED_LINE}), scaled by ray "
+                          f"segments to rank 0's profiled step of this {world}-GPU run: rank 0 traces the same paths"}
     except Exception:
         return None
 
@@ -329,7 +359,8 @@ def roofline(c, pmc):
         useful = k["SQ_INSTS_VALU"] * 64.0 * lane_util * scale     # lane-operations that did work
         issued = k["SQ_INSTS_VALU"] * 64.0 * scale                 # lane slots the issued instructions occupied
         achieved = useful / ext_s
-        r.update({"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s (f64-rate VALU)",
+        r.update({"measured": not pmc.get("committed", False),   # false: counters of the committed N = 1 line, not of this run
+                  "bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s (f64-rate VALU)",
                   "frac": achieved / VALU_PEAK_LANE_OPS,
                   "valu": {"lane_utilisation": lane_util, "issue_frac": issued / ext_s / VALU_PEAK_LANE_OPS,
                            "valu_wave_insts_per_segment": k["SQ_INSTS_VALU"] / ch["segments"],
@@ -356,7 +387,7 @@ def roofline(c, pmc):
     else:
         # no counters from this run: the fraction that needs none (lane accesses against the measured gather rate) is the
         # headline, and the line says why
-        r.update({"bound": "l1_lane_access", "achieved": lane_acc, "peak": 1.1, "unit": "lane accesses/clk/CU", "frac": lane_acc / 1.1,
+        r.update({"measured": True, "bound": "l1_lane_access", "achieved": lane_acc, "peak": 1.1, "unit": "lane accesses/clk/CU", "frac": lane_acc / 1.1,
                   "traffic": None, "pmc": {"source": "none", "reason": (pmc or {}).get("error", "PMC passes not run (--no-pmc or N > 1)")}})
     return r
 

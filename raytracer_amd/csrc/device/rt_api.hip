@@ -46,7 +46,7 @@ hipStream_t g_stream = nullptr;       // the current device's stream (g_dev[g_de
 // what rt_init keeps per device: the library's stream, two events for the pipelined queue-length read-back, and the device
 // address of the static workspace of rt_render_device_noalloc (every GPU holds its own copy of the array at its own address)
 #define RT_MAX_DEVICES 64
-struct DevState { hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; unsigned char* scratch = nullptr; };
+struct DevState { hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; unsigned char* scratch = nullptr; bool ready = false; };
 DevState g_dev[RT_MAX_DEVICES];
 uint32_t g_extend_blocks = 2048;      // fixed grids: 2048 x 128 threads = 16 waves on each of 256 CUs
 uint32_t g_stream_blocks = 4096;
@@ -385,7 +385,9 @@ int render_dynamic(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s
     { const int rca = check_render_args(sc, cam, algorithm, max_depth, d_fb); if (rca) return rca; }
     const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
     uint32_t k = 0;
-    { const int rcw = size_workspace(sc, WH, s_count, max_depth, &k); if (rcw) return rcw; }
+    // an empty render (no samples, or camera.rs:155-157's depth 0) only clears the framebuffer: one sample's worth of workspace,
+    // not "as many samples as HBM holds" (s_count 0 means that to size_workspace)
+    { const int rcw = size_workspace(sc, WH, (s_count && max_depth) ? s_count : 1u, max_depth, &k); if (rcw) return rcw; }
     return render_impl(sc, sc->ws, k, cam, algorithm, s_begin, s_count, max_depth, seed, d_fb, st, stats);
 }
 
@@ -403,17 +405,24 @@ int rt_init(int device) {
     if (device >= RT_MAX_DEVICES) return fail(RT_E_LIMIT, "device %d: this library keeps state for %d devices", device, RT_MAX_DEVICES);
     HIPCHECK(hipSetDevice(device));
     DevState& dv = g_dev[device];
-    if (!dv.stream) {                                 // first rt_init on this device; a later one finds its stream again
-        HIPCHECK(hipStreamCreateWithFlags(&dv.stream, hipStreamNonBlocking));
-        HIPCHECK(hipEventCreateWithFlags(&dv.ev[0], hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&dv.ev[1], hipEventDisableTiming));
+    if (!dv.ready) {                                  // first rt_init on this device; a later one finds its state again
+        // built into a local and committed only when every step succeeded: a failed rt_init leaves the device un-initialised
+        // (and what it did create released), so a retry starts over instead of finding half a state
+        DevState nv;
+        auto undo = [&]() { if (nv.ev[0]) (void)hipEventDestroy(nv.ev[0]); if (nv.ev[1]) (void)hipEventDestroy(nv.ev[1]); if (nv.stream) (void)hipStreamDestroy(nv.stream); };
+        hipError_t e2 = hipStreamCreateWithFlags(&nv.stream, hipStreamNonBlocking);
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&nv.ev[0], hipEventDisableTiming);
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&nv.ev[1], hipEventDisableTiming);
         // rt_render_device_noalloc's workspace: the array's name is a host-side stand-in, its device address is looked up once
         // per device, with that device current
         void* p = nullptr;
-        HIPCHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        dv.scratch = (unsigned char*)p;
+        if (e2 == hipSuccess) e2 = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e2 != hipSuccess || !p) { undo(); return fail(RT_E_HIP, "rt_init(%d): device set-up failed: %s", device, hipGetErrorString(e2)); }
+        nv.scratch = (unsigned char*)p; nv.ready = true;
+        dv = nv;
     }
     g_stream = dv.stream; g_device = device;
+    g_batch_paths = 0;                                // every rt_init re-reads the environment: an unset variable means the default again
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
@@ -481,6 +490,8 @@ void rt_scene_destroy(rt_scene* sc) {
             fprintf(stderr, "[stamps] cycles per phase call: refill %.0f internal %.0f leaf %.0f | lanes per call: refill %.1f internal %.1f leaf %.1f | live lanes/iteration %.1f\n",
                     h[5] ? (double)h[1] / h[5] : 0.0, h[6] ? (double)h[2] / h[6] : 0.0, h[7] ? (double)h[3] / h[7] : 0.0,
                     h[5] ? (double)h[10] / h[5] : 0.0, h[6] ? (double)h[8] / h[6] : 0.0, h[7] ? (double)h[9] / h[7] : 0.0, h[4] ? (double)h[11] / h[4] : 0.0);
+            fprintf(stderr, "[stamps] internal phases on one pair (wave-uniform): %.4f of the phases, %.4f of the lane visits; >= 3/4 of the lanes on the first lane's pair: %.4f of the phases\n",
+                    h[6] ? (double)h[13] / h[6] : 0.0, h[8] ? (double)h[14] / h[8] : 0.0, h[6] ? (double)h[15] / h[6] : 0.0);
             (void)hipMemset(g_dbg, 0, sizeof h);
         }
     }

@@ -9,7 +9,8 @@
 //   * the node slices ("segments") of a level are contiguous ranges of one dense array of objects.  A stable radix sort of the
 //     whole array by centroid key followed by a stable sort by segment number sorts every segment by that axis, ties keeping
 //     their current order — exactly what `slice::sort_by` does per node;
-//   * prefix and suffix boxes are segmented scans (f64 min/max are exact, so the association does not matter); the cost of every
+//   * prefix and suffix boxes are segmented scans (f64 min/max are exact and, written as BoxUnion / BoxUnionRev below, resolve
+//     equal planes — signed zeros — to the object the reference's left fold would keep); the cost of every
 //     split position is then one expression per element, and the first minimum per segment is a segmented min-scan on
 //     (cost, position);
 //   * a per-segment kernel compares the three axes in order with the reference's strict `<`, writes the children and the next
@@ -31,10 +32,26 @@
 namespace rtb {
 
 struct Box6 { double mn[3], mx[3]; };
+// f64::min / f64::max as the host builder and the oracle evaluate them (std::fmin / std::fmax on x86-64): of two equal operands
+// — only +0 and -0 are equal and distinguishable — the SECOND is returned, and a NaN operand yields the other one.  The device's
+// own fmin (v_min_f64) orders -0 below +0 instead, so a box plane that is a zero could come out with the other sign.
+__host__ __device__ inline double min_tie2(double a, double b) { return (a < b || b != b) ? a : b; }
+__host__ __device__ inline double max_tie2(double a, double b) { return (a > b || b != b) ? a : b; }
+// objects_to_aabb (hittable_list.rs:123-133) is a left fold, acc = acc + next: `a` is the fold so far, `b` the next object.  With
+// min_tie2 the fold returns the LAST of equal minima, which is associative, so a parallel scan reproduces it bit for bit.
 struct BoxUnion {
     __host__ __device__ Box6 operator()(const Box6& a, const Box6& b) const {            // aabb.rs:134-147
         Box6 r;
-        for (int c = 0; c < 3; ++c) { r.mn[c] = fmin(a.mn[c], b.mn[c]); r.mx[c] = fmax(a.mx[c], b.mx[c]); }
+        for (int c = 0; c < 3; ++c) { r.mn[c] = min_tie2(a.mn[c], b.mn[c]); r.mx[c] = max_tie2(a.mx[c], b.mx[c]); }
+        return r;
+    }
+};
+// The suffix boxes are a prefix scan over the REVERSED array: `a` holds objects that stand later in the slice than `b`.  The
+// reference folds the right child's slice left to right (bvh.rs:151), so equal planes must again resolve to the later object: `a`.
+struct BoxUnionRev {
+    __host__ __device__ Box6 operator()(const Box6& a, const Box6& b) const {
+        Box6 r;
+        for (int c = 0; c < 3; ++c) { r.mn[c] = min_tie2(b.mn[c], a.mn[c]); r.mx[c] = max_tie2(b.mx[c], a.mx[c]); }
         return r;
     }
 };
@@ -178,8 +195,8 @@ __global__ void k_prim_setup(const rt_prim* __restrict__ prims, const double* __
         for (int c = 0; c < 3; ++c) { b.mn[c] = p.v[c] - p.v[3]; b.mx[c] = p.v[c] + p.v[3]; }
     } else {                                             // triangle.rs:83-92
         for (int c = 0; c < 3; ++c) {
-            b.mn[c] = fmin(fmin(p.v[c], p.v[3 + c]), p.v[6 + c]);
-            b.mx[c] = fmax(fmax(p.v[c], p.v[3 + c]), p.v[6 + c]);
+            b.mn[c] = min_tie2(min_tie2(p.v[c], p.v[3 + c]), p.v[6 + c]);
+            b.mx[c] = max_tie2(max_tie2(p.v[c], p.v[3 + c]), p.v[6 + c]);
         }
     }
     boxes[i] = b;
@@ -282,7 +299,7 @@ int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node
             tb = tmp_bytes;
             RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, segidx, fwd, pre[a], BoxUnion(), (int)M, SegEq(), st));
             tb = tmp_bytes;
-            RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, rev_seg, rev, suf[a], BoxUnion(), (int)M, SegEq(), st));
+            RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, rev_seg, rev, suf[a], BoxUnionRev(), (int)M, SegEq(), st));
             hipLaunchKernelGGL(k_cost, blocks(M), dim3(TB), 0, st, pre[a], suf[a], segidx, sb, sc, M, cand);
             tb = tmp_bytes;
             RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, segidx, cand, best[a], CandMin(), (int)M, SegEq(), st));
@@ -473,7 +490,7 @@ __global__ void k_grid_boxes(const rt_prim* __restrict__ prims, uint32_t n, Box6
     if (i >= n) return;
     const rt_prim p = prims[i]; Box6 b;
     if (p.type == RT_SPHERE) { for (int c = 0; c < 3; ++c) { b.mn[c] = p.v[c] - p.v[3]; b.mx[c] = p.v[c] + p.v[3]; } }
-    else for (int c = 0; c < 3; ++c) { b.mn[c] = fmin(fmin(p.v[c], p.v[3 + c]), p.v[6 + c]); b.mx[c] = fmax(fmax(p.v[c], p.v[3 + c]), p.v[6 + c]); }
+    else for (int c = 0; c < 3; ++c) { b.mn[c] = rtb::min_tie2(rtb::min_tie2(p.v[c], p.v[3 + c]), p.v[6 + c]); b.mx[c] = rtb::max_tie2(rtb::max_tie2(p.v[c], p.v[3 + c]), p.v[6 + c]); }
     boxes[i] = b;
 }
 __global__ void k_grid_origin_list(const uint32_t* __restrict__ in_origin, const uint32_t* __restrict__ rank, uint32_t n, uint32_t* __restrict__ origin_list) {

@@ -259,13 +259,14 @@ template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, co
 // Diagnostic build only (-DRT_STAMPS): per-wave cycle sums per phase of the loop, added into dbg[] at the end.
 // dbg: 0 loop cycles, 1 refill cycles, 2 internal cycles, 3 leaf cycles, 4 iterations, 5 refill iterations, 6 internal
 // iterations, 7 leaf iterations, 8 lanes served by internal phases, 9 lanes served by leaf phases, 10 lanes refilled,
-// 11 live lanes summed over iterations, 12 waves
+// 11 live lanes summed over iterations, 12 waves, 13 internal phases whose lanes all stand on ONE pair (what a scalar-load
+// path could serve), 14 lanes in those, 15 internal phases where at least 3/4 of the lanes stand on the first lane's pair
 #ifdef RT_STAMPS
-#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0; const unsigned long long tk_begin = clock64();
-#define RT_STAMP(x) x
+#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0, n_uni = 0, l_uni = 0, n_uni2 = 0; const unsigned long long tk_begin = clock64();
+#define RT_STAMP(...) __VA_ARGS__
 #else
 #define RT_STAMP_DECL
-#define RT_STAMP(x)
+#define RT_STAMP(...)
 #endif
 // wave64 ballot of a predicate that already lives in a lane mask: one s_and with exec (HIP's __ballot(int) first
 // materialises the bool as 0/1 in a VGPR and compares it again)
@@ -404,6 +405,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
             RT_STAMP(l_live += n_int + n_leaf; tk0 = clock64();)
             if (!(n_leaf == 0 || (n_int != 0 && n_int * cost_leaf >= n_leaf * cost_int))) break;   // never starve: one side is non-empty
             // ---- one internal-node visit (bvh.rs:203-229), branch-free apart from the push
+            RT_STAMP({ const bool on_int = cur_b == 0u; const unsigned long long mi = ballot64(on_int);
+                       const uint32_t ua = (uint32_t)__shfl((int)cur_a, (int)__builtin_ctzll(mi), 64); const unsigned long long df = ballot64(on_int && cur_a != ua);
+                       n_uni += df == 0 ? 1 : 0; l_uni += df == 0 ? n_int : 0; n_uni2 += popc64(df) * 4u <= n_int ? 1 : 0; })
             if (cur_b == 0u) {
                 ++c_int;                                 // bvh.rs:190 (and two box tests, bvh.rs:183)
                 double dLmn[3], dLmx[3], dRmn[3], dRmx[3];          // box planes minus the ray origin (aabb.rs:36-37)
@@ -416,6 +420,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     dRmn[0] = lattice_minus(q1.z, scale, o.x); dRmn[1] = lattice_minus(q1.w, scale, o.y); dRmn[2] = lattice_minus(q2.x, scale, o.z);
                     dRmx[0] = lattice_minus(q2.y, scale, o.x); dRmx[1] = lattice_minus(q2.z, scale, o.y); dRmx[2] = lattice_minus(q2.w, scale, o.z);
                     La = q3.x; Lb = q3.y; Ra = q3.z; Rb = q3.w;
+#ifdef RT_PROBE_L1
+                    // sensitivity probe (never in the product build): RT_PROBE_L1 more 16-byte lane accesses per visit, from the previous
+                    // record (another cache line half of the time); the value is consumed by an empty asm so the load stays
+                    for (int e = 0; e < RT_PROBE_L1; ++e) { uint4 x = pp[-1 - e]; /* the previous record (pair indices start at 1): in bounds */ asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+#endif
+#ifdef RT_PROBE_VALU
+                    // sensitivity probe: RT_PROBE_VALU more 32-bit VALU instructions per visit (the v_bfe_i32 / v_bfi_b32 / v_cndmask
+                    // mix a 48-byte "new planes + selector bits" record would need to rebuild the two boxes)
+                    { uint32_t j0 = q3.x, j1 = q0.x, j2 = q1.x;
+#pragma unroll
+                      for (int e = 0; e < RT_PROBE_VALU / 3; ++e)
+                          asm volatile("v_bfe_i32 %0, %1, 3, 1\n\tv_bfi_b32 %1, %0, %2, %1\n\tv_bfi_b32 %2, %0, %1, %2" : "+v"(j0), "+v"(j1), "+v"(j2));
+                      asm volatile("" :: "v"(j0), "v"(j1), "v"(j2)); }
+#endif
                 } else {                                 // 112-byte pair: seven accesses
                     const double2* pp = (const double2*)(bvh.pairs64 + cur_a);
                     const double2 b0 = pp[0], b1 = pp[1], b2 = pp[2], b3 = pp[3], b4 = pp[4], b5 = pp[5];
@@ -521,8 +539,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     }
 #ifdef RT_STAMPS
     if (dbg && lane == 0) {
-        const unsigned long long v[13] = {clock64() - tk_begin, tk_ref, tk_int, tk_leaf, n_it, n_ref, n_intp, n_leafp, l_int, l_leaf, l_ref, l_live, 1};
-        for (int i = 0; i < 13; ++i) atomicAdd(&dbg[i], v[i]);
+        const unsigned long long v[16] = {clock64() - tk_begin, tk_ref, tk_int, tk_leaf, n_it, n_ref, n_intp, n_leafp, l_int, l_leaf, l_ref, l_live, 1, n_uni, l_uni, n_uni2};
+        for (int i = 0; i < 16; ++i) atomicAdd(&dbg[i], v[i]);
     }
 #endif
     if (stats) {

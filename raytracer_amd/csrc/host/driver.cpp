@@ -168,8 +168,9 @@ struct Accel { bool have_bvh = false, have_grid = false; Bvh bvh; Grid grid; };
 // build on the GPU with --gpu-build), rt_render.  `sum` receives W*H*3 partial sums.
 int render_slice(const Cli& cli, const Scene& scene, const Accel& acc, const rt_camera& rc, uint32_t max_depth, bool draw_boxes, int device,
                  uint32_t s_begin, uint32_t s_count, double* sum, rt_stats* st, double* init_seconds, std::string& err) {
-    auto start = std::chrono::steady_clock::now();
     if (rt_init(device) != RT_OK) { err = rt_last_error(); return 3; }
+    // init_time covers world.init() (main.rs:126-129): upload + flatten / GPU build, not HIP start-up (context, code object)
+    auto start = std::chrono::steady_clock::now();
     rt_scene* dev = rt_scene_create(scene.prims.data(), (uint32_t)scene.prims.size(), scene.mats.data(), (uint32_t)scene.mats.size());
     if (!dev) { err = rt_last_error(); return 3; }
     auto fail_hip = [&]() { err = rt_last_error(); rt_scene_destroy(dev); return 3; };

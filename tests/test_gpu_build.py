@@ -50,6 +50,29 @@ def test_gpu_bvh_single_object_and_duplicates(gpu):
     assert np.array_equal(dev[1], host[1]) and dev[0].tobytes() == host[0].tobytes()
 
 
+def test_gpu_bvh_signed_zeros_and_coincident_boxes(gpu):
+    """The adversarial input of tests/test_oracle_sweep.py (duplicate centroids, coincident and zero-area boxes, +0 / -0 planes)
+    through rt_bvh_build: the right child's box is a left fold of its slice (bvh.rs:61-64,150-151), and of two equal planes
+    f64::min / f64::max keep the later object's — the sign of a zero plane included.  Held to the oracle's LITERAL builder."""
+    from oracle.oracle_py import OracleScene
+    rng = np.random.default_rng(5); n = 600
+    p = np.zeros(n, dtype=[("type", "<u4"), ("material", "<u4"), ("v", "<f8", (9,))]); p["type"] = 1
+    grid = rng.integers(-3, 4, size=(n, 3)).astype(np.float64)
+    v = grid[:, None, :] + rng.choice([0.0, -0.0, 0.5, 1.0], size=(n, 3, 3))
+    v[::7] = np.where(v[::7] == 0.0, -0.0, v[::7])
+    p["v"] = v.reshape(n, 9)
+    cent = np.round(v.mean(axis=1))
+    mats = np.zeros(1, dtype=[("type", "<u4"), ("pad", "<u4"), ("albedo", "<f8", (3,)), ("param", "<f8")])
+    assert np.signbit(v[v == 0.0]).any() and not np.signbit(v[v == 0.0]).all(), "the input must hold both zeros"
+    w = HittableList.from_arrays(p, cent, mats)
+    host, dev, _ = both(w)
+    on, oo = OracleScene(w.prims(), w.centroids(), w.materials()).build_bvh("sah-position").get_bvh()
+    assert np.array_equal(dev[1], oo), "object order"
+    assert host[0].tobytes() == on.tobytes(), "host builder vs the oracle's literal builder"
+    bad = [i for i in range(len(on)) if dev[0][i].tobytes() != on[i].tobytes()]
+    assert not bad, f"GPU-built nodes {bad[:8]} differ from the oracle's literal builder: {dev[0][bad[0]]} vs {on[bad[0]]}"
+
+
 def test_gpu_bvh_full_size_mesh_and_time(gpu):
     """The bench mesh (764 704 triangles): identical to the host build; the time is printed for DESIGN.md."""
     w = HittableList.from_ply("scenes/dragon_recon/dragon_vrip_res3.ply", subdivide=2)

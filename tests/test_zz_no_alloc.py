@@ -55,6 +55,68 @@ def test_noalloc_other_walks(gpu, scene, algorithm, grid_size):
     w.close()
 
 
+def test_noalloc_allocates_nothing(gpu):
+    """The property the entry point is named for: free device memory (hipMemGetInfo, through torch) is the same before and after
+    the call, on a scene whose own workspace has never been created — so neither a hipMalloc'd workspace, nor a grown event
+    pool, nor anything else that takes device memory can hide in it.  The first call of a process loads the kernels' code
+    object (HIP does that lazily), so one warm-up call on another scene comes first."""
+    warm = weekend_mixed(); warm.algorithm = "bvh"; warm.init().upload()  # same kind of scene: the same kernel instantiations
+    fb = torch.zeros((270, 480, 3), dtype=torch.float64, device="cuda")
+    Camera(warm.filename, image_width=64, samples_per_pixel=1).render(warm, d_out=fb.data_ptr(), noalloc=True)
+    w = weekend_mixed(); w.algorithm = "bvh"; w.init().upload()          # fresh scene: rt_render_device has never run on it
+    cam = Camera(w.filename, image_width=480, samples_per_pixel=3)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    _, s1 = cam.render(w, seed=3, d_out=fb.data_ptr(), noalloc=True)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    _, s2 = Camera(w.filename, image_width=96, samples_per_pixel=2).render(w, seed=4, d_out=fb.data_ptr(), noalloc=True)
+    torch.cuda.synchronize()
+    free2 = torch.cuda.mem_get_info()[0]
+    assert free1 == free0 and free2 == free0, f"free device memory moved across rt_render_device_noalloc: {free0} -> {free1} -> {free2}"
+    assert s1["primary_rays"] == 480 * 270 * 3 and s2["primary_rays"] == 96 * 54 * 2
+    # the allocating entry point on the same scene does take memory (the check above can see a workspace)
+    cam.render(w, seed=3, d_out=fb.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free0
+    w.close(); warm.close()
+
+
+def test_noalloc_depth_zero_and_no_samples(gpu):
+    """camera.rs:155-157: max_depth 0 is black before world.hit is called; s_count 0 is an empty sum.  Both leave through the
+    memset path of the bounce loop, which the static workspace must take as well."""
+    w = load_world("simple_fuzzy_metal"); w.algorithm = "bvh"; w.init().upload()
+    for kw in ({"max_depth": 0, "samples_per_pixel": 2}, {"samples_per_pixel": 2}):
+        cam = Camera(w.filename, image_width=64, **kw)
+        fa = torch.full((cam.image_height, 64, 3), -1.0, dtype=torch.float64, device="cuda"); fb = fa.clone()
+        s_count = None if "max_depth" in kw else 0
+        _, sa = cam.render(w, seed=9, s_count=s_count, d_out=fa.data_ptr())
+        _, sb = cam.render(w, seed=9, s_count=s_count, d_out=fb.data_ptr(), noalloc=True)
+        torch.cuda.synchronize()
+        assert torch.equal(fa, fb) and float(fb.abs().sum()) == 0.0
+        for k in KEYS:
+            assert sa[k] == sb[k], (k, sa[k], sb[k])
+    w.close()
+
+
+def test_noalloc_on_a_callers_stream(gpu):
+    """A non-NULL stream argument: the call's kernels are ordered on the caller's stream, after the work already queued there."""
+    w = load_world("triangle_materials"); w.algorithm = "bvh"; w.init().upload()
+    cam = Camera(w.filename, image_width=160, samples_per_pixel=2)
+    ref = torch.zeros((cam.image_height, 160, 3), dtype=torch.float64, device="cuda")
+    _, sa = cam.render(w, seed=12, d_out=ref.data_ptr())
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out = torch.full_like(ref, 7.0)                       # queued on s: the render must come after this fill
+        _, sb = cam.render(w, seed=12, d_out=out.data_ptr(), stream=s.cuda_stream, noalloc=True)
+        doubled = out * 2.0                                   # and this after the render
+    s.synchronize()
+    assert torch.equal(out, ref) and torch.equal(doubled, ref * 2.0)
+    for k in KEYS:
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+    w.close()
+
+
 def test_noalloc_limits_are_errors(gpu):
     w = load_world("simple_fuzzy_metal"); w.algorithm = "bvh"; w.init().upload()
     fb = torch.zeros((540, 960, 3), dtype=torch.float64, device="cuda")

@@ -3,14 +3,15 @@
 # usage: tools/profile.sh <tag> [bench args...]; results under gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:-"--steps 1 --warmup 0 --spp-per-gpu 8 --no-cpu-baseline --no-pmc"}
+# --no-pmc --pmc-child are always appended: bench.py must not start rocprofv3 passes of its own under this profiler, and runs exactly one step
+ARGS=${@:-"--steps 1 --warmup 0 --spp-per-gpu 8 --no-cpu-baseline"}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 echo "$ARGS" > $OUT/args.txt
 export TMPDIR=/tmp
 run() { # name, rocprof flags...
   local name=$1; shift
-  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $OUT/$name -o $name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1
+  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $OUT/$name -o $name -- python3 bench.py $ARGS --no-pmc --pmc-child > $OUT/$name.log 2>&1
   local rc=$?; echo "$name rc=$rc"; return $rc
 }
 run trace --kernel-trace --stats || exit 1
