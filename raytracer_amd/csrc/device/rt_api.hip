@@ -62,6 +62,8 @@ bool g_tri_pre = true;                // RT_TRI_PRE=0: naive / grid walks recomp
 bool g_bounce_log = false;            // RT_BOUNCE_LOG=1: per-bounce kernel times on stderr while profiling is on
 bool g_cell_tri = true;               // RT_CELL_TRI=0: the grid walk reads list entry -> plane record instead of the per-position records (A/B)
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
+bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
+                                      // measured 8.5 % slower on the headline workload (profiles/round3_extend_variants.md), kept for the A/B
 
 struct EventPool {
     std::vector<hipEvent_t> ev; size_t used = 0;
@@ -123,6 +125,7 @@ struct rt_scene {
     uint32_t stack_blocks = 0;         // extend blocks d_stack was sized for (RT_EXTEND_BLOCKS may change between rt_init calls)
     DPair32* d_pairs32 = nullptr; DPrim32* d_prims32 = nullptr; double lattice_scale = 0.0;   // compact forms; scale 0 = not available
     DPair64* d_pairs64 = nullptr; DSphere* d_spheres = nullptr;                               // generic pairs; spheres only for all-sphere scenes
+    DPairN* d_pairsn = nullptr; uint32_t root_own[6] = {0, 0, 0, 0, 0, 0};                    // new-planes-only pairs (two accesses per visit), when the tree allows
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     // grid
     bool have_grid = false; DGrid grid{}; rt_grid_desc grid_desc{}; uint64_t grid_list_len = 0;
@@ -190,9 +193,12 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         else {
             BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs64 = sc->d_pairs64; v.spheres = sc->d_spheres;
             v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
+            v.pairsn = sc->d_pairsn; for (int f = 0; f < 6; ++f) v.root_own[f] = sc->root_own[f];
             const bool c32 = g_compact && sc->lattice_scale > 0.0, sph = g_compact && sc->d_spheres != nullptr;
+            const bool cn = c32 && g_pairn && sc->d_pairsn != nullptr;
 #define RT_LAUNCH_BVH2(N, P, T) hipLaunchKernelGGL((k_extend_bvh2<N, P, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, d_stats, g_dbg)
-            if (c32)      { if (out.trace) RT_LAUNCH_BVH2(1, 1, true); else RT_LAUNCH_BVH2(1, 1, false); }
+            if (cn)       { if (out.trace) RT_LAUNCH_BVH2(2, 1, true); else RT_LAUNCH_BVH2(2, 1, false); }
+            else if (c32) { if (out.trace) RT_LAUNCH_BVH2(1, 1, true); else RT_LAUNCH_BVH2(1, 1, false); }
             else if (sph) { if (out.trace) RT_LAUNCH_BVH2(0, 2, true); else RT_LAUNCH_BVH2(0, 2, false); }
             else          { if (out.trace) RT_LAUNCH_BVH2(0, 0, true); else RT_LAUNCH_BVH2(0, 0, false); }
 #undef RT_LAUNCH_BVH2
@@ -426,6 +432,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_BATCH_PATHS")) { unsigned long long v = strtoull(s, nullptr, 10); if (v >= 4096) g_batch_paths = v; }
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
+    g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
     if (const char* s = getenv("RT_LG_SAMPLES")) { int v = atoi(s); if (v >= 0 && v <= 7) g_lg_samples = v; }
     if (const char* s = getenv("RT_TRI_PRE")) g_tri_pre = atoi(s) != 0;
     if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
@@ -436,7 +443,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_ACC_THREADS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 64 && v <= RT_SBLOCK && v % 64 == 0) g_acc_threads = (uint32_t)v; }
     if (const char* s = getenv("RT_EXTEND_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_extend_blocks = (uint32_t)v & ~7u; }
 #ifdef RT_STAMPS
-    if (!g_dbg) { HIPCHECK(hipMalloc(&g_dbg, 16 * sizeof(unsigned long long))); HIPCHECK(hipMemset(g_dbg, 0, 16 * sizeof(unsigned long long))); }
+    if (!g_dbg) { HIPCHECK(hipMalloc(&g_dbg, 24 * sizeof(unsigned long long))); HIPCHECK(hipMemset(g_dbg, 0, 24 * sizeof(unsigned long long))); }
 #endif
     g_inited = true;
     return RT_OK;
@@ -483,7 +490,7 @@ void rt_scene_destroy(rt_scene* sc) {
     (void)hipDeviceSynchronize();
 #ifdef RT_STAMPS
     if (g_dbg) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         if (hipMemcpy(h, g_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[12]) {
             fprintf(stderr, "[stamps] waves %llu | cycles/wave: loop %.3g refill %.3g internal %.3g leaf %.3g | iterations/wave %.0f (refill %.0f internal %.0f leaf %.0f)\n",
                     h[12], (double)h[0] / h[12], (double)h[1] / h[12], (double)h[2] / h[12], (double)h[3] / h[12], (double)h[4] / h[12], (double)h[5] / h[12], (double)h[6] / h[12], (double)h[7] / h[12]);
@@ -492,6 +499,7 @@ void rt_scene_destroy(rt_scene* sc) {
                     h[5] ? (double)h[10] / h[5] : 0.0, h[6] ? (double)h[8] / h[6] : 0.0, h[7] ? (double)h[9] / h[7] : 0.0, h[4] ? (double)h[11] / h[4] : 0.0);
             fprintf(stderr, "[stamps] internal phases on one pair (wave-uniform): %.4f of the phases, %.4f of the lane visits; >= 3/4 of the lanes on the first lane's pair: %.4f of the phases\n",
                     h[6] ? (double)h[13] / h[6] : 0.0, h[8] ? (double)h[14] / h[8] : 0.0, h[6] ? (double)h[15] / h[6] : 0.0);
+            fprintf(stderr, "[stamps] continuations that entered an internal node (DPairN box re-fetches): %llu = %.4f per internal visit\n", h[16], h[17] ? (double)h[16] / h[17] : 0.0);
             (void)hipMemset(g_dbg, 0, sizeof h);
         }
     }
@@ -499,7 +507,7 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->d_prims) (void)hipFree(sc->d_prims); if (sc->d_mats) (void)hipFree(sc->d_mats); if (sc->d_tri_pre) (void)hipFree(sc->d_tri_pre);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
     if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
-    if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres);
+    if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres); if (sc->d_pairsn) (void)hipFree(sc->d_pairsn);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
     if (sc->d_cell_tri) (void)hipFree(sc->d_cell_tri);
     sc->ws.release();
@@ -528,7 +536,8 @@ int rt_scene_bvh_layout(const rt_scene* sc, uint32_t* pair_bytes, uint32_t* prim
     if (!sc || !sc->have_bvh) return fail(RT_E_STATE, "rt_scene_set_bvh() has not been called");
     const bool persistent = !sc->draw_boxes && g_extend_variant == 2 && !sc->bvh_empty_leaf;
     const bool c32 = persistent && g_compact && sc->lattice_scale > 0.0, sph = persistent && g_compact && sc->d_spheres != nullptr;
-    if (pair_bytes) *pair_bytes = c32 ? (uint32_t)sizeof(DPair32) : (persistent ? (uint32_t)sizeof(DPair64) : 2u * (uint32_t)sizeof(DNode));
+    const bool cn = c32 && g_pairn && sc->d_pairsn != nullptr;      // 32 of the record's 64 bytes per visit (the other 32 only when a continuation enters an internal node)
+    if (pair_bytes) *pair_bytes = cn ? 32u : c32 ? (uint32_t)sizeof(DPair32) : (persistent ? (uint32_t)sizeof(DPair64) : 2u * (uint32_t)sizeof(DNode));
     if (prim_bytes) *prim_bytes = c32 ? (uint32_t)sizeof(DPrim32) : (sph ? (uint32_t)sizeof(DSphere) : (uint32_t)sizeof(DPrim));
     return RT_OK;
 }
@@ -573,8 +582,8 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     for (uint32_t k = 0; k < n; ++k) dp[k] = to_dprim(sc->h_prims[prim_index[k]], prim_index[k]);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes); if (sc->d_prims_bvh) (void)hipFree(sc->d_prims_bvh); if (sc->d_stack) (void)hipFree(sc->d_stack);
     if (sc->d_pairs32) (void)hipFree(sc->d_pairs32); if (sc->d_prims32) (void)hipFree(sc->d_prims32);
-    if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres);
-    sc->d_pairs64 = nullptr; sc->d_spheres = nullptr;
+    if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres); if (sc->d_pairsn) (void)hipFree(sc->d_pairsn);
+    sc->d_pairs64 = nullptr; sc->d_spheres = nullptr; sc->d_pairsn = nullptr;
     sc->d_nodes = nullptr; sc->d_prims_bvh = nullptr; sc->d_stack = nullptr; sc->d_pairs32 = nullptr; sc->d_prims32 = nullptr; sc->lattice_scale = 0.0; sc->have_bvh = false;
     HIPCHECK(hipMalloc(&sc->d_nodes, dn.size() * sizeof(DNode)));
     HIPCHECK(hipMalloc(&sc->d_prims_bvh, dp.size() * sizeof(DPrim)));
@@ -640,6 +649,47 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
         HIPCHECK(hipMemcpy(sc->d_pairs32, pairs.data(), pairs.size() * sizeof(DPair32), hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(sc->d_prims32, tris.data(), tris.size() * sizeof(DPrim32), hipMemcpyHostToDevice));
         sc->lattice_scale = S;
+        // new-planes-only records (DPairN, rt_device.h): every face of a node's box must be one child's plane bit for bit, and the
+        // tree must fit the packed child words; otherwise the scene keeps DPair32
+        {
+            std::vector<DPairN> pn(pairs.size());
+            for (auto& r : pn) memset(&r, 0, sizeof r);
+            bool okn = pairs.size() < (1u << 24) && n < (1u << 24);
+            auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+            auto word = [&](uint32_t a, uint32_t b, bool& good) -> uint32_t {
+                if (b & RT_LEAF) { const uint32_t cnt = b & 0x3fffffffu; if (cnt > 15u || a >= (1u << 24)) good = false; return RT_LEAF | (a << 4) | (cnt & 15u); }
+                if (a >= (1u << 24)) good = false;
+                return a << 4;
+            };
+            for (size_t di = 1; okn && di <= n_nodes; ++di) {
+                const DNode& X = dn[di];
+                if (X.b & RT_LEAF) continue;
+                const size_t p = X.a >> 1;                              // X's children are device nodes X.a, X.a + 1 = pair p
+                const DPair32& q = pairs[p]; DPairN& r = pn[p];
+                float own[6]; bool lat = true;
+                for (int c = 0; c < 3; ++c) lat = lat && on_lattice(X.mn[c], S, own[c]) && on_lattice(X.mx[c], S, own[3 + c]);
+                if (!lat) { okn = false; break; }
+                uint32_t sel = 0;
+                for (int f = 0; f < 6; ++f) {
+                    const uint32_t P = bits(own[f]), L = bits(q.box[f]), R = bits(q.box[6 + f]);
+                    r.own[f] = P;
+                    if (L == P) r.nw[f] = R;                                 // the right child owns the new plane
+                    else if (R == P) { r.nw[f] = L; sel |= 1u << f; }        // the left child does
+                    else okn = false;
+                }
+                r.wl = word(q.la, q.lb, okn) | ((sel & 7u) << 28);
+                r.wr = word(q.ra, q.rb, okn) | (((sel >> 3) & 7u) << 28);
+            }
+            if (okn) {
+                float ro[6];
+                for (int c = 0; c < 3; ++c) okn = okn && on_lattice(dn[1].mn[c], S, ro[c]) && on_lattice(dn[1].mx[c], S, ro[3 + c]);
+                for (int f = 0; f < 6; ++f) sc->root_own[f] = bits(ro[f]);
+            }
+            if (okn) {
+                HIPCHECK(hipMalloc(&sc->d_pairsn, pn.size() * sizeof(DPairN)));
+                HIPCHECK(hipMemcpy(sc->d_pairsn, pn.data(), pn.size() * sizeof(DPairN), hipMemcpyHostToDevice));
+            }
+        }
         break;
     }
     for (int c = 0; c < 3; ++c) { sc->root_mn[c] = nodes[0].min[c]; sc->root_mx[c] = nodes[0].max[c]; }

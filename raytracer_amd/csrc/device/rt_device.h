@@ -185,6 +185,23 @@ struct __align__(16) DPair64 { double box[12]; uint32_t la, lb, ra, rb; };     /
 struct __align__(16) DSphere { double c[3]; double r; uint32_t tm, orig, pad0, pad1; };
 struct __align__(16) DPair32 { float box[12]; uint32_t la, lb, ra, rb; };      // box: L.mn, L.mx, R.mn, R.mx
 struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; };          // triangles only
+// DPairN: a sibling pair in TWO 16-byte accesses.  A node's box is the union of its children's boxes (objects_to_aabb folds
+// min/max, hittable_list.rs:123-133), so on each of the six faces (mn.x, mn.y, mn.z, mx.x, mx.y, mx.z) at least one child's
+// plane IS the parent's plane, bit for bit; the record keeps only the other child's plane on that face ("new" plane) and one
+// selector bit saying which child owns it.  The lane carries the box of the node it stands on (six f32 words, the planes it
+// tested on the way down) and rebuilds both children's planes with one bit-field select each; the values it then computes with
+// are the very f32 lattice planes the 64-byte DPair32 holds.  A divergent 16-byte lane access is what the vector L1 serves at
+// about one per clock and CU (profiles/round1_mb_gather.txt), and one more access per visit costs the extend kernel +28 %.
+// MEASURED (profiles/round3_extend_variants.md): the waves wait less (0.54 -> 0.43 of their cycles) but the rebuild's ~44 VALU
+// per visit push VALU issue from 0.67 to 0.80 and the step is 8.5 % slower.  Opt-in (RT_PAIRN=1), not the default.
+//   nw[0..5]  new plane per face, f32 bits
+//   wl, wr    child words: bit 31 leaf | bits 28-30 selector bits (wl: faces 0-2, wr: faces 3-5; 1 = the LEFT child owns the
+//             new plane) | bits 4-27 pair index of the child's children / first primitive of a leaf | bits 0-3 leaf count
+//   own[0..5] the box of the node whose children this record describes (f32 bits): read only when a popped continuation
+//             enters an internal node, whose box the lane no longer holds
+// Only for lattice scenes whose tree fits the fields (< 2^24 pairs and primitives, leaves of <= 15) and whose planes inherit
+// bit for bit (a +0 / -0 pair of equal planes would not): anything else keeps DPair32.
+struct __align__(16) DPairN { uint32_t nw[6]; uint32_t wl, wr; uint32_t own[6]; uint32_t pad0, pad1; };
 
 // The part of HitRecord (hittable.rs:13-21) that survives a hit() call and that later code reads:
 // rec.t (read back as closest_so_far, bvh.rs:200,215 / grid.rs:164), the t at which rec.p was last written

@@ -41,9 +41,9 @@ template <bool DRAW>
 __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, const uint32_t* count, uint64_t n_fixed,
                              double tmin0, double tmax0, ExtendOut out, StackEntry* stack, unsigned long long* stats);
 // tree and primitives as the persistent extend kernel reads them (rt_device.h):
-//   NODES 0 = DPair64 (f64 planes), 1 = DPair32 (lattice);  PRIMS 0 = DPrim (any mix), 1 = DPrim32 (lattice triangles), 2 = DSphere
+//   NODES 0 = DPair64 (f64 planes), 1 = DPair32 (lattice), 2 = DPairN (lattice, new planes only: two accesses per visit);  PRIMS 0 = DPrim (any mix), 1 = DPrim32 (lattice triangles), 2 = DSphere
 struct BvhView { const DNode* nodes; const DPrim* prims; const DPair64* pairs64; const DSphere* spheres;
-                 const DPair32* pairs32; const DPrim32* prims32; double scale; };
+                 const DPair32* pairs32; const DPrim32* prims32; double scale; const DPairN* pairsn; uint32_t root_own[6]; };
 template <int NODES, int PRIMS, bool TRACE>
 __global__ void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);

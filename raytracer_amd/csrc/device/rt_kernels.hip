@@ -262,7 +262,7 @@ template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, co
 // 11 live lanes summed over iterations, 12 waves, 13 internal phases whose lanes all stand on ONE pair (what a scalar-load
 // path could serve), 14 lanes in those, 15 internal phases where at least 3/4 of the lanes stand on the first lane's pair
 #ifdef RT_STAMPS
-#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0, n_uni = 0, l_uni = 0, n_uni2 = 0; const unsigned long long tk_begin = clock64();
+#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0, n_uni = 0, l_uni = 0, n_uni2 = 0, n_refetch = 0; const unsigned long long tk_begin = clock64();
 #define RT_STAMP(...) __VA_ARGS__
 #else
 #define RT_STAMP_DECL
@@ -319,6 +319,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     const DNode* __restrict__ nodes = bvh.nodes; const DPrim* __restrict__ prims = bvh.prims;
     const DNode root = nodes[1];                 // device node i+1 = host node i (pairs 128-byte aligned)
     const uint32_t root_a = (root.b & RT_LEAF) ? root.a : root.a >> 1;       // internal: index of its children's pair
+    bool need_box = false;                       // NODES == 2: pbox must be read from the record at the next visit
+    uint32_t pbox[6] = {0, 0, 0, 0, 0, 0};       // NODES == 2: the box of the node the lane stands on, f32 bits per face (DPairN)
     const double scale = bvh.scale;
 
     // Rays are taken from the queue 64 at a time into registers (lane i holds ray pf_base + i) while the wave is still
@@ -381,6 +383,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
                     tmax = tmax0; sp = 0; lo = 0; flag = false;
                     if ((pf_hit >> src) & 1ull) { cur_a = root_a; cur_b = root.b; }      // a root miss was answered when its batch was finished
+                    if (NODES == 2) {
+                        need_box = false;
+#pragma unroll
+                        for (int f = 0; f < 6; ++f) pbox[f] = bvh.root_own[f];
+                    }
                 }
                 const uint32_t taken = (n_idle < avail) ? n_idle : avail;
                 pf_pos += taken;
@@ -412,7 +419,29 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 ++c_int;                                 // bvh.rs:190 (and two box tests, bvh.rs:183)
                 double dLmn[3], dLmx[3], dRmn[3], dRmx[3];          // box planes minus the ray origin (aabb.rs:36-37)
                 uint32_t La, Lb, Ra, Rb;
-                if (NODES == 1) {                        // 64-byte pair: four 16-byte accesses
+                uint32_t nLp[6], nRp[6];                 // NODES == 2: the children's planes as f32 bits, kept for the next level's pbox
+                if (NODES == 2) {                        // 32-byte record of new planes: two 16-byte accesses
+                    const uint4* pp = (const uint4*)(bvh.pairsn + cur_a);
+                    const uint4 r0 = pp[0], r1 = pp[1];
+                    if (need_box) {                      // entered through a popped continuation: the node's own box rides in the same record
+                        const uint4 b0 = pp[2], b1 = pp[3];      // (same cache line, same round trip)
+                        pbox[0] = b0.x; pbox[1] = b0.y; pbox[2] = b0.z; pbox[3] = b0.w; pbox[4] = b1.x; pbox[5] = b1.y;
+                        need_box = false;
+                        RT_STAMP(++n_refetch;)
+                    }
+                    const uint32_t nw[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) {
+                        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)(f < 3 ? r1.z : r1.w), 28 + f % 3, 1);   // all ones: the left child owns the new plane
+                        nLp[f] = (m & nw[f]) | (~m & pbox[f]);                                                  // v_bfi_b32
+                        nRp[f] = (m & pbox[f]) | (~m & nw[f]);
+                    }
+                    dLmn[0] = lattice_minus(nLp[0], scale, o.x); dLmn[1] = lattice_minus(nLp[1], scale, o.y); dLmn[2] = lattice_minus(nLp[2], scale, o.z);
+                    dLmx[0] = lattice_minus(nLp[3], scale, o.x); dLmx[1] = lattice_minus(nLp[4], scale, o.y); dLmx[2] = lattice_minus(nLp[5], scale, o.z);
+                    dRmn[0] = lattice_minus(nRp[0], scale, o.x); dRmn[1] = lattice_minus(nRp[1], scale, o.y); dRmn[2] = lattice_minus(nRp[2], scale, o.z);
+                    dRmx[0] = lattice_minus(nRp[3], scale, o.x); dRmx[1] = lattice_minus(nRp[4], scale, o.y); dRmx[2] = lattice_minus(nRp[5], scale, o.z);
+                    La = __builtin_amdgcn_ubfe(r1.z, 4, 24); Lb = r1.z & 0x8000000fu; Ra = __builtin_amdgcn_ubfe(r1.w, 4, 24); Rb = r1.w & 0x8000000fu;
+                } else if (NODES == 1) {                 // 64-byte pair: four 16-byte accesses
                     const uint4* pp = (const uint4*)(bvh.pairs32 + cur_a);
                     const uint4 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3];
                     dLmn[0] = lattice_minus(q0.x, scale, o.x); dLmn[1] = lattice_minus(q0.y, scale, o.y); dLmn[2] = lattice_minus(q0.z, scale, o.z);
@@ -461,6 +490,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 }
                 cur_a = go_right ? Ra : La;
                 cur_b = (lh || rh) ? (go_right ? Rb : Lb) : RT_POP;
+                if (NODES == 2) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) pbox[f] = go_right ? nRp[f] : nLp[f];
+                }
             }
             RT_STAMP(++n_intp; l_int += n_int; tk_int += clock64() - tk0;)
         }
@@ -532,6 +565,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     resume(se);
                 }
             }
+            if (NODES == 2 && cur_b == 0u) need_box = true;     // a continuation entered an internal node: the lane no longer holds its box
             if (done) store_hit<SH_MODE>(out, q, rec.prim >= 0, rec, prims);
         }
         look_for_rays = ballot64(done) != 0;
@@ -542,6 +576,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
         const unsigned long long v[16] = {clock64() - tk_begin, tk_ref, tk_int, tk_leaf, n_it, n_ref, n_intp, n_leafp, l_int, l_leaf, l_ref, l_live, 1, n_uni, l_uni, n_uni2};
         for (int i = 0; i < 16; ++i) atomicAdd(&dbg[i], v[i]);
     }
+    if (dbg) {   // per-lane counts (every lane adds its own)
+        const unsigned long long rf = wave_sum(n_refetch), ci = wave_sum(c_int);
+        if (lane == 0) { atomicAdd(&dbg[16], rf); atomicAdd(&dbg[17], ci); }
+    }
 #endif
     if (stats) {
         stat_add(stats, ST_BOX, (uint64_t)c_int * 2u + c_rays); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, (uint64_t)c_int + c_leaf);
@@ -549,7 +587,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     }
 }
 #define RT_INST_BVH2(N, P, T) template __global__ void k_extend_bvh2<N, P, T>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
-RT_INST_BVH2(0, 0, false) RT_INST_BVH2(0, 0, true) RT_INST_BVH2(0, 2, false) RT_INST_BVH2(0, 2, true) RT_INST_BVH2(1, 1, false) RT_INST_BVH2(1, 1, true)
+RT_INST_BVH2(0, 0, false) RT_INST_BVH2(0, 0, true) RT_INST_BVH2(0, 2, false) RT_INST_BVH2(0, 2, true) RT_INST_BVH2(1, 1, false) RT_INST_BVH2(1, 1, true) RT_INST_BVH2(2, 1, false) RT_INST_BVH2(2, 1, true)
 
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
 // per-triangle constants of hit_triangle_pre (all-triangle scenes only)

@@ -275,6 +275,21 @@ def test_compact_lattice_layout_is_chosen_for_ply_and_is_bit_identical(gpu, monk
     compact = w.hit(ro, rd)
     assert_trace_equal(plain, ref, "f64 layout")
     assert_trace_equal(compact, ref, "compact layout")
+    # the opt-in 32-byte "new planes only" sibling record (DPairN, RT_PAIRN=1): two accesses per visit, same bits, same counters
+    try:
+        monkeypatch.setenv("RT_PAIRN", "1"); rt.init(0); w.upload()
+        assert w.bvh_layout() == (32, 48)
+        pn = w.hit(ro, rd)
+        cam = Camera(w.filename, image_width=160, samples_per_pixel=3)
+        img_n, st_n = cam.render(w, seed=4)
+    finally:
+        monkeypatch.delenv("RT_PAIRN"); rt.init(0)
+    w.upload()
+    img_c, st_c = cam.render(w, seed=4)
+    assert_trace_equal(pn, ref, "new-planes layout")
+    assert np.array_equal(img_n, img_c)
+    for k in ("scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb", "ray_segments"):
+        assert st_n[k] == st_c[k], k
     w.close()
     # JSON scenes carry arbitrary f64 coordinates: no lattice; f64 pairs (112 B), 48-B spheres when there is nothing else
     j = load_world("weekend-5-80-15"); j.algorithm = "bvh"; j.init(); j.upload()
