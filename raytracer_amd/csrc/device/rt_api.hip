@@ -62,6 +62,8 @@ bool g_tri_pre = true;                // RT_TRI_PRE=0: naive / grid walks recomp
 bool g_bounce_log = false;            // RT_BOUNCE_LOG=1: per-bounce kernel times on stderr while profiling is on
 bool g_cell_tri = true;               // RT_CELL_TRI=0: the grid walk reads list entry -> plane record instead of the per-position records (A/B)
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
+uint32_t g_grid_coop_share_num = 1, g_grid_coop_share_den = 2;   // ... and only if such cells hold at least this share of all list entries (RT_GRID_COOP_SHARE, percent)
+uint32_t g_grid_coop_min = 128;       // RT_GRID_COOP_MIN: cells whose list has at least this many triangles are tested by the whole wave (k_extend_grid_coop); 0 = never
 bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
                                       // measured 8.5 % slower on the headline workload (profiles/round3_extend_variants.md), kept for the A/B
 
@@ -131,6 +133,7 @@ struct rt_scene {
     bool have_grid = false; DGrid grid{}; rt_grid_desc grid_desc{}; uint64_t grid_list_len = 0;
     double* d_cell_aabb = nullptr; uint64_t* d_cell_offset = nullptr; uint32_t* d_prim_list = nullptr;
     DCellTri* d_cell_tri = nullptr;    // all-triangle scenes: plane record + index per list position (k_cell_tri)
+    uint32_t* d_cell_chunk = nullptr; DCellChunk* d_chunks = nullptr; uint32_t n_chunks = 0;   // cooperative cell test: chunked lists of the well-filled cells
     Workspace ws;
 };
 
@@ -214,6 +217,8 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         const DTriPre* gpre = (sc->grid_list_len * 10ull >= sc->grid.n_cells) ? sc->d_tri_pre : nullptr;
         if (sc->draw_boxes)
             hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, d_stats);
+        else if (sc->n_chunks && sc->d_tri_pre)          // some cells are well filled: the whole wave tests their lists (all-triangle scenes)
+            hipLaunchKernelGGL(k_extend_grid_coop, grid, block, 0, st, sc->grid, sc->d_prims, sc->d_tri_pre, in, count, n_fixed, tmin, tmax, out, d_stats);
         else
             hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, d_stats);
         break;
@@ -433,6 +438,9 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
+    g_grid_coop_min = 128; if (const char* s = getenv("RT_GRID_COOP_MIN")) g_grid_coop_min = (uint32_t)strtoul(s, nullptr, 10);
+    g_grid_coop_share_num = 1; g_grid_coop_share_den = 2;
+    if (const char* s = getenv("RT_GRID_COOP_SHARE")) { g_grid_coop_share_num = (uint32_t)strtoul(s, nullptr, 10); g_grid_coop_share_den = 100; }
     if (const char* s = getenv("RT_LG_SAMPLES")) { int v = atoi(s); if (v >= 0 && v <= 7) g_lg_samples = v; }
     if (const char* s = getenv("RT_TRI_PRE")) g_tri_pre = atoi(s) != 0;
     if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
@@ -510,6 +518,7 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres); if (sc->d_pairsn) (void)hipFree(sc->d_pairsn);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
     if (sc->d_cell_tri) (void)hipFree(sc->d_cell_tri);
+    if (sc->d_cell_chunk) (void)hipFree(sc->d_cell_chunk); if (sc->d_chunks) (void)hipFree(sc->d_chunks);
     sc->ws.release();
     delete sc;
 }
@@ -714,6 +723,42 @@ static void install_grid(rt_scene* sc, const rt_grid_desc& gd, uint64_t list_len
         if (hipStreamSynchronize(g_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sc->d_cell_tri); sc->d_cell_tri = nullptr; }
     } else (void)hipGetLastError();
     g.cell_tri = sc->d_cell_tri;
+    // cooperative cell test: chunk the lists of the cells that hold at least g_grid_coop_min triangles (optional: any failure
+    // leaves the per-lane walk in charge)
+    if (sc->d_cell_chunk) { (void)hipFree(sc->d_cell_chunk); sc->d_cell_chunk = nullptr; }
+    if (sc->d_chunks) { (void)hipFree(sc->d_chunks); sc->d_chunks = nullptr; }
+    sc->n_chunks = 0; g.cell_chunk = nullptr; g.chunks = nullptr;
+    if (g_grid_coop_min && sc->d_tri_pre && list_len >= g_grid_coop_min && gd.n_cells < 0xffffffffull) {
+        std::vector<uint64_t> off(gd.n_cells + 1);
+        if (hipMemcpy(off.data(), sc->d_cell_offset, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<uint32_t> cell_chunk(gd.n_cells, RT_NO_CHUNK), big_cells, big_first;
+            uint64_t n_chunks = 0, big_entries = 0;
+            for (uint64_t c = 0; c < gd.n_cells; ++c) {
+                const uint64_t len = off[c + 1] - off[c];
+                if (len >= g_grid_coop_min && len <= 0xffffffffull) { cell_chunk[c] = (uint32_t)n_chunks; big_cells.push_back((uint32_t)c); big_first.push_back((uint32_t)n_chunks); n_chunks += (len + 63) / 64; big_entries += len; }
+            }
+            // the cooperative kernel pays for its parking rounds with occupancy (3 waves per SIMD instead of 4); where most list entries
+            // sit in short lists (fine grids: res4 at size 1 has 3 such cells among 1016 populated ones) the per-lane walk stays in charge
+            if (big_entries * g_grid_coop_share_den < list_len * g_grid_coop_share_num) n_chunks = 0;
+            uint32_t *d_big = nullptr, *d_first = nullptr;
+            if (n_chunks && n_chunks * sizeof(DCellChunk) <= (8ull << 30)
+                && hipMalloc(&sc->d_cell_chunk, gd.n_cells * sizeof(uint32_t)) == hipSuccess && hipMalloc(&sc->d_chunks, n_chunks * sizeof(DCellChunk)) == hipSuccess
+                && hipMalloc(&d_big, big_cells.size() * sizeof(uint32_t)) == hipSuccess && hipMalloc(&d_first, big_first.size() * sizeof(uint32_t)) == hipSuccess
+                && hipMemcpy(sc->d_cell_chunk, cell_chunk.data(), gd.n_cells * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess
+                && hipMemcpy(d_big, big_cells.data(), big_cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess
+                && hipMemcpy(d_first, big_first.data(), big_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess) {
+                hipLaunchKernelGGL(k_cell_chunks, dim3((unsigned)n_chunks), dim3(64), 0, g_stream, sc->d_cell_offset, sc->d_prim_list, d_big, d_first, (uint32_t)big_cells.size(),
+                                   sc->d_prims, sc->d_tri_pre, sc->d_chunks, (uint32_t)n_chunks);
+                if (hipStreamSynchronize(g_stream) == hipSuccess) { sc->n_chunks = (uint32_t)n_chunks; g.cell_chunk = sc->d_cell_chunk; g.chunks = sc->d_chunks; }
+            }
+            if (d_big) (void)hipFree(d_big); if (d_first) (void)hipFree(d_first);
+            if (!sc->n_chunks) {
+                (void)hipGetLastError();
+                if (sc->d_cell_chunk) { (void)hipFree(sc->d_cell_chunk); sc->d_cell_chunk = nullptr; }
+                if (sc->d_chunks) { (void)hipFree(sc->d_chunks); sc->d_chunks = nullptr; }
+            }
+        } else (void)hipGetLastError();
+    }
     sc->grid_desc = gd; sc->grid_list_len = list_len;
     sc->have_grid = true;
 }

@@ -346,6 +346,12 @@ RT_DEV bool hit_triangle_cell(const DPrim* __restrict__ prims, const DCellTri& q
     return true;
 }
 
+// The list of a well-filled grid cell, 64 entries at a time, one field after the other (SoA): lane l of a wave reads entry l
+// of every field, so each load instruction of the cooperative cell test (k_extend_grid_coop) is one contiguous 256- or
+// 512-byte run.  n / dd are the triangle's plane as k_tri_pre computes it (triangle.rs:39-41,50), v its vertices, pi its index.
+// Entries past the end of the list have n = 0: n.d = 0 fails `0.001 < n.d` (triangle.rs:44-47), so they do nothing.
+struct __align__(128) DCellChunk { double n[3][64]; double dd[64]; double v[9][64]; uint32_t pi[64]; uint32_t pad[64]; };
+
 RT_DEV bool hit_prim(const DPrim& p, int32_t index, V3 o, V3 d, double tmin, double tmax, HitState& rec) {
     return (p.tm >> 31) ? hit_triangle(p, index, o, d, tmin, tmax, rec) : hit_sphere(p, index, o, d, tmin, tmax, rec);
 }

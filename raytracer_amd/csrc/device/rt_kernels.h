@@ -28,7 +28,11 @@ struct DGrid {
     V3 box_size, origin, end, total_size; uint64_t n_cells; uint32_t max_depth;
     const double* cell_aabb; const uint64_t* cell_offset; const uint32_t* prim_list;
     const DCellTri* cell_tri;      // nullable: per list position, the triangle's plane record and index (all-triangle scenes)
+    // cooperative cell test (k_extend_grid_coop; all-triangle scenes): cells whose list has at least coop_min entries keep it a
+    // second time as 64-entry SoA chunks; cell_chunk[cell] = index of the cell's first chunk, RT_NO_CHUNK for the other cells
+    const uint32_t* cell_chunk; const DCellChunk* chunks;
 };
+#define RT_NO_CHUNK 0xffffffffu
 
 enum { ST_SCATTER = 0, ST_BOX, ST_PRIM, ST_STEPS, ST_OVERLAP, ST_GRIDBOX, ST_SEGMENTS, ST_N };
 
@@ -54,6 +58,10 @@ __global__ void k_extend_naive(const DPrim* prims, const DTriPre* pre, uint32_t 
 template <bool DRAW>
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, const DTriPre* pre, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
+__global__ void k_cell_chunks(const uint64_t* cell_offset, const uint32_t* prim_list, const uint32_t* big_cells, const uint32_t* big_first, uint32_t n_big,
+                              const DPrim* prims, const DTriPre* pre, DCellChunk* chunks, uint32_t n_chunks);
+__global__ void k_extend_grid_coop(DGrid g, const DPrim* prims, const DTriPre* pre, RayQ in, const uint32_t* count, uint64_t n_fixed,
+                                   double tmin0, double tmax0, ExtendOut out, unsigned long long* stats);
 __global__ void k_shade(const DPrim* prims, const DMat* mats, uint32_t n_mats, RayQ in, const uint32_t* count_in,
                         const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,
                         double* rad, uint32_t WH, uint32_t s_base, uint32_t s_count, uint32_t bounce, uint32_t max_depth, uint64_t seed,

@@ -779,6 +779,234 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
 template __global__ void k_extend_grid<false>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
 template __global__ void k_extend_grid<true>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
 
+// ---------------------------------------------------------------------------------------------
+// extend_grid, cooperative form (all-triangle scenes whose grid has well-filled cells).  The cell walk of Grid::traverse
+// (grid.rs:151-183) stays one ray per lane; what changes is GridBox::hit (grid.rs:281-294) for a cell with a long list.  The
+// per-lane loop walks such a list with every lane at its own entry (divergent loads) and runs the edge tests whenever any
+// lane's triangle passes the plane test, i.e. always, with a third of the lanes (lane utilisation 0.27-0.33, 60-70 % of the wave
+// cycles waiting: profiles/round2_res4_grid*_summary.md).  Here a lane that reaches such a cell PARKS; when no lane of the wave
+// can walk on, the parked rays are served one after the other by the WHOLE wave: the ray is broadcast (readlane -> scalar
+// registers), lane l tests entry l of the current 64-entry chunk of the list (coalesced SoA loads, DCellChunk), and the
+// reference's sequential semantics are re-established per chunk by a short scalar loop:
+//   * closest_so_far only changes when a triangle is ACCEPTED (grid.rs:288-291), and only the `n.d < closest` half of the plane
+//     test reads it (triangle.rs:44-47), so every lane evaluates its entry once and the acceptance chain is resolved in list
+//     order on ballots: entries up to the first accepted one are final under the current closest, the rest are re-compared
+//     (one v_cmp) under the new one;
+//   * rec.t is the t of the LAST entry that passed the plane test, rec.p's parameter that of the last one that also had t >= 0
+//     (triangle.rs:52,59 write before acceptance), the primitive / normal those of the last accepted entry.
+// Every counter is what the per-lane walk counts (one primitive test per list entry).
+RT_DEV double rl_f64(double x, uint32_t k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), (int)k), __builtin_amdgcn_readlane(__double2loint(x), (int)k));
+}
+// one thread per (chunk, entry): gather the list entry's plane record, vertices and index
+__global__ void k_cell_chunks(const uint64_t* __restrict__ cell_offset, const uint32_t* __restrict__ prim_list, const uint32_t* __restrict__ big_cells,
+                              const uint32_t* __restrict__ big_first, uint32_t n_big, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
+                              DCellChunk* __restrict__ chunks, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x, l = threadIdx.x;                       // 64 threads per block
+    if (c >= n_chunks) return;
+    uint32_t lo = 0, hi = n_big;                                         // last big cell whose first chunk is <= c
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (big_first[mid] <= c) lo = mid; else hi = mid; }
+    const uint32_t cell = big_cells[lo];
+    const uint64_t e = cell_offset[cell] + (uint64_t)(c - big_first[lo]) * 64u + l, end = cell_offset[cell + 1];
+    DCellChunk& ch = chunks[c];
+    if (e < end) {
+        const uint32_t pi = prim_list[e];
+        const DTriPre q = pre[pi]; const DPrim tr = prims[pi];
+        ch.n[0][l] = q.n[0]; ch.n[1][l] = q.n[1]; ch.n[2][l] = q.n[2]; ch.dd[l] = q.dd;
+        for (int k = 0; k < 9; ++k) ch.v[k][l] = tr.v[k];
+        ch.pi[l] = pi;
+    } else {
+        ch.n[0][l] = 0.0; ch.n[1][l] = 0.0; ch.n[2][l] = 0.0; ch.dd[l] = 0.0;
+        for (int k = 0; k < 9; ++k) ch.v[k][l] = 0.0;
+        ch.pi[l] = 0u;
+    }
+    ch.pad[l] = 0u;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
+                                                               RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+                                                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
+    __shared__ double2 s_ray[RT_BLOCK / 64][3][64];                     // origins and directions of the wave's parked rays
+    const uint64_t n = count ? (uint64_t)*count : n_fixed;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (RT_BLOCK / 64);
+    const uint64_t wave0 = (uint64_t)xcd_chunk(blockIdx.x, gridDim.x) * (RT_BLOCK / 64) + (threadIdx.x >> 6);
+    const double INF = __builtin_huge_val();
+    uint64_t c_box = 0, c_prim = 0, c_steps = 0, c_gbox = 0, c_rays = 0;
+    for (uint64_t base = wave0 * 64u; base < n; base += n_waves * 64u) {          // wave-uniform: 64 consecutive rays per pass
+        const uint64_t q = base + lane;
+        const bool valid = q < n;
+        V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
+        if (valid) { o = v3(in.ox[q], in.oy[q], in.oz[q]); d = v3(in.dx[q], in.dy[q], in.dz[q]); }
+        const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+        bool hit = false;
+        uint64_t cell = 0;
+        bool walking = false;
+        if (valid) {
+            ++c_rays;
+            cell = grid_cell_from_point(o, g);                          // get_box_enter (grid.rs:119-129)
+            walking = cell < g.n_cells;
+            if (!walking) {
+                double mn[3] = {g.origin.x, g.origin.y, g.origin.z}, mx[3] = {g.end.x, g.end.y, g.end.z};
+                double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+                double a = 0.001, b = INF; bool ok = true;
+                for (int ax = 0; ax < 3; ++ax) {                        // AABB::enter_and_exit (aabb.rs:65-88)
+                    double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
+                    if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) b = t1; }
+                    else { if (t1 > a) a = t1; if (t0 < b) b = t0; }
+                    if (b <= a) { ok = false; break; }
+                }
+                if (ok) { cell = grid_cell_from_point(o + d * a, g); walking = cell < g.n_cells; }
+            }
+        }
+        uint32_t depth = 0;
+        // state of the cell the lane stands in, kept while it is parked
+        bool parked = false, any = false;
+        double cell_b = 0.0, cmn0 = 0.0, cmn1 = 0.0, cmn2 = 0.0; int ex_axis = 0, ex_dir = 0;
+        uint32_t pk_chunk = 0, pk_len = 0;
+        double cp_t = 0.0, cp_tp = 0.0, cp_tn = 0.0, cp_cl = 0.0; int32_t cp_prim = -1;   // the copy of rec after the cell's list (grid.rs:160-162); cp_cl = closest_so_far of a parked ray
+        // grid.rs:163-181 after the cell's objects were tested: take the copy, stop on a hit inside the cell, else step
+        auto leave_cell = [&]() {
+            if (any) {
+                rec.t = cp_t; rec.tp = cp_tp; rec.tn = cp_tn; rec.prim = cp_prim;
+                if (rec.t <= cell_b) { hit = true; walking = false; return; }
+            }
+            ++c_box;                                                   // grid.rs:172
+            V3 step = v3(0, 0, 0);                                     // aabb.rs:161-165
+            const double sv = (double)ex_dir * (ex_axis == 0 ? g.box_size.x : (ex_axis == 1 ? g.box_size.y : g.box_size.z));
+            if (ex_axis == 0) step.x = sv; else if (ex_axis == 1) step.y = sv; else step.z = sv;
+            const V3 next_xyz = v3(cmn0, cmn1, cmn2) + step;
+            const bool inside = g.origin.x <= next_xyz.x && g.end.x >= next_xyz.x && g.origin.y <= next_xyz.y && g.end.y >= next_xyz.y
+                             && g.origin.z <= next_xyz.z && g.end.z >= next_xyz.z;   // grid.rs:186-192
+            if (!inside) { walking = false; return; }
+            cell = grid_index(next_xyz - g.origin, g);                 // grid.rs:76-83
+            if (cell >= g.n_cells) walking = false;
+            ++depth;
+        };
+        for (;;) {
+            // ---- phase A: every lane walks until it is done or stands in a cell with a chunked list
+            while (ballot64(walking) != 0) {
+                if (walking) {
+                    if (depth > g.max_depth) { walking = false; }      // grid.rs:152
+                    else {
+                        ++c_steps;
+                        const double* cb = g.cell_aabb + cell * 6;
+                        double mn[3] = {cb[0], cb[1], cb[2]}, mx[3] = {cb[3], cb[4], cb[5]};
+                        double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+                        double a = -INF, b = INF; bool ok = true; ex_axis = 0; ex_dir = 0;
+                        for (int ax = 0; ax < 3; ++ax) {                // AABB::hit with Interval::universe keeping the Exit (aabb.rs:28-62)
+                            double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
+                            if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) { b = t1; ex_axis = ax; ex_dir = 1; } }
+                            else { if (t1 > a) a = t1; if (t0 < b) { b = t0; ex_axis = ax; ex_dir = -1; } }
+                            if (b < a) { ok = false; break; }
+                        }
+                        if (!ok) { walking = false; }                  // grid.rs:155-156
+                        else {
+                            ++c_gbox;
+                            cell_b = b; cmn0 = mn[0]; cmn1 = mn[1]; cmn2 = mn[2];
+                            const uint64_t lo = g.cell_offset[cell], hi = g.cell_offset[cell + 1];
+                            const uint32_t ck = g.cell_chunk[cell];
+                            any = false;
+                            if (ck != RT_NO_CHUNK) {                   // long list: wait for the wave
+                                parked = true; walking = false; pk_chunk = ck; pk_len = (uint32_t)(hi - lo);
+                            } else {                                   // short list: GridBox::hit on a copy of rec (grid.rs:160-167, 281-294), lane by lane
+                                HitState copy = rec;
+                                double closest = tmax0;
+                                if (g.cell_tri) {
+                                    for (uint64_t k = lo; k < hi; ++k) { ++c_prim; const DCellTri ct = g.cell_tri[k]; if (hit_triangle_cell(prims, ct, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; } }
+                                } else {
+                                    for (uint64_t k = lo; k < hi; ++k) { ++c_prim; const uint32_t pi = g.prim_list[k]; if (hit_triangle_pre(prims, pre, pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; } }
+                                }
+                                cp_t = copy.t; cp_tp = copy.tp; cp_tn = copy.tn; cp_prim = copy.prim;
+                                leave_cell();
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- phase B: the parked rays.  Rays that stand in the same cell form a group; each 64-entry chunk of the cell's list is
+            // loaded once (lane l = entry l) and tested against every ray of the group in turn, the ray coming from its lane through
+            // readlane (scalar registers) and its running GridBox::hit state (closest_so_far, the copy's t / p parameter / primitive)
+            // living in that lane's own registers between chunks.
+            unsigned long long pm = ballot64(parked);
+            if (pm == 0) break;
+            if (parked) {
+                cp_t = rec.t; cp_tp = rec.tp; cp_prim = rec.prim; cp_cl = tmax0; any = false;
+                s_ray[wv][0][lane] = make_double2(o.x, o.y); s_ray[wv][1][lane] = make_double2(o.z, d.x); s_ray[wv][2][lane] = make_double2(d.y, d.z);
+            }
+            wave_sync();
+            while (pm != 0) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(pm);
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)pk_chunk, (int)k), len = (uint32_t)__builtin_amdgcn_readlane((int)pk_len, (int)k);
+                const unsigned long long grp = ballot64(parked && pk_chunk == c0);      // a cell's first chunk index names the cell
+                pm &= ~grp;
+                const uint32_t nch = (len + 63u) >> 6;
+                if ((grp >> lane) & 1ull) c_prim += len;
+                for (uint32_t j = 0; j < nch; ++j) {
+                    const DCellChunk* ch = g.chunks + (c0 + j);
+                    const V3 nn = v3(ch->n[0][lane], ch->n[1][lane], ch->n[2][lane]);
+                    const double dd = ch->dd[lane];
+                    const V3 v0 = v3(ch->v[0][lane], ch->v[1][lane], ch->v[2][lane]), v1 = v3(ch->v[3][lane], ch->v[4][lane], ch->v[5][lane]);
+                    const V3 v2 = v3(ch->v[6][lane], ch->v[7][lane], ch->v[8][lane]);
+                    const uint32_t pi = ch->pi[lane];
+                    const V3 v0v1 = v1 - v0, v1v2 = v2 - v1, v2v0 = v0 - v2;               // triangle.rs:61,66,71: ray-independent, once per chunk
+                    for (unsigned long long gm = grp; gm != 0; gm &= gm - 1ull) {
+                        const uint32_t r = (uint32_t)__builtin_ctzll(gm);
+                        // the ray comes out of LDS (same address for every lane: a broadcast read on the LDS pipe) rather than through
+                        // twelve v_readlane on the VALU; closest_so_far changes between chunks and stays a readlane
+                        const double2 r0 = s_ray[wv][0][r], r1 = s_ray[wv][1][r], r2 = s_ray[wv][2][r];
+                        const V3 ko = v3(r0.x, r0.y, r1.x), kd = v3(r1.y, r2.x, r2.y);
+                        double closest = rl_f64(cp_cl, r);
+                        const double nd = dot(nn, kd);                      // triangle.rs:43
+                        const bool a = tmin0 < nd;                          // the half of :44-47 that does not read closest_so_far
+                        const double t = -(dot(nn, ko) + dd) / nd;          // :50-52
+                        const bool tpos = !(t < 0.0);                       // :55-57
+                        bool E = false;
+                        if (ballot64(a && tpos) != 0) {                     // :59-75, for every lane (a wave runs them for one lane as for all)
+                            const V3 p = ko + (t * kd);
+                            const V3 v0p = p - v0, v1p = p - v1, v2p = p - v2;
+                            const bool e0 = !(dot(nn, cross(v0v1, v0p)) <= 0.0);
+                            const bool e1 = !(dot(nn, cross(v1v2, v1p)) <= 0.0);
+                            const bool e2 = !(dot(nn, cross(v2v0, v2p)) <= 0.0);
+                            E = e0 && e1 && e2;
+                        }
+                        const unsigned long long Mtp = ballot64(tpos), Mok = ballot64(tpos && E);
+                        double u_t = 0.0, u_tp = 0.0; int32_t u_prim = -1; bool u_acc = false, u_have_t = false, u_have_tp = false;
+                        unsigned long long rem = ~0ull;
+                        while (rem != 0) {                                  // the acceptance chain of this chunk, in list order
+                            const unsigned long long C1 = ballot64(a && nd < closest) & rem;
+                            const unsigned long long A = C1 & Mok;
+                            unsigned long long fin = C1;
+                            uint32_t k2 = 0;
+                            if (A != 0) { k2 = (uint32_t)__builtin_ctzll(A); const unsigned long long upto = (k2 == 63u) ? ~0ull : ((2ull << k2) - 1ull); fin = C1 & upto; rem &= ~upto; }
+                            else rem = 0;
+                            if (fin != 0) {
+                                u_t = rl_f64(t, 63u - (uint32_t)__builtin_clzll(fin)); u_have_t = true;
+                                const unsigned long long F2 = fin & Mtp;
+                                if (F2 != 0) { u_tp = rl_f64(t, 63u - (uint32_t)__builtin_clzll(F2)); u_have_tp = true; }
+                            }
+                            if (A != 0) { closest = rl_f64(t, k2); u_prim = __builtin_amdgcn_readlane((int)pi, (int)k2); u_acc = true; }
+                        }
+                        if (lane == r) {
+                            if (u_have_t) cp_t = u_t;
+                            if (u_have_tp) cp_tp = u_tp;
+                            if (u_acc) { cp_cl = closest; cp_prim = u_prim; any = true; }
+                        }
+                    }
+                }
+            }
+            if (parked) cp_tn = any ? cp_cl : rec.tn;
+            if (parked) { parked = false; walking = true; leave_cell(); }
+        }
+        if (valid) store_hit(out, q, hit, rec, prims, false);
+    }
+    if (stats) {
+        stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
+        stat_add(stats, ST_GRIDBOX, c_gbox); stat_add(stats, ST_SEGMENTS, c_rays);
+    }
+}
+
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 6      // 80 VGPRs: three 512-thread blocks per CU instead of two (shade 59 -> 56.5 ms; 8 spills and is slower)
 #endif

@@ -518,3 +518,74 @@ def test_random_scenes_render_matches_oracle(gpu, seed, algorithm, grid_size):
     assert np.array_equal(np.isfinite(img), fin)
     assert np.max(np.abs(img[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300), initial=0.0) <= RADIANCE_RTOL
     w.close()
+
+
+def _triangle_soup(seed, n, spread, stacked, center=(0.0, 0.0, -6.0)):
+    """All-triangle scene for the cooperative grid test (k_extend_grid_coop): `n` triangles crowded into a few grid cells so that
+    their lists are chunked (>= 64 entries).  `stacked` adds runs of parallel, equally wound triangles one behind the other: a ray
+    through a run is ACCEPTED several times within one 64-entry chunk (closest_so_far changes mid-chunk, grid.rs:288-291), in
+    ascending and in descending order of t — and zero-area, coincident and back-facing triangles sit in between."""
+    from raytracer_amd import HittableList
+    from raytracer_amd.host import _MAT_DT, _PRIM_DT
+    rng = np.random.default_rng(seed)
+    prims = np.zeros(n, _PRIM_DT); prims["type"] = 1
+    ctr = np.array(center)
+    c = rng.uniform(-spread, spread, size=(n, 3)) + ctr
+    tri = c[:, None, :] + rng.normal(scale=rng.choice([1e-9, 0.4, 1.5, 4.0], size=(n, 1, 1)), size=(n, 3, 3))
+    flat = rng.random(n) < 0.05
+    tri[flat, 2] = tri[flat, 1]                                          # zero area
+    for s in range(stacked):                                             # runs of 12 parallel triangles facing the camera side
+        i0 = int(rng.integers(0, n - 12)); base = rng.normal(scale=min(2.5, 2.0 * spread), size=(3, 3)) + ctr
+        order = np.arange(12) if s % 2 == 0 else np.arange(12)[::-1]
+        for j, dz in enumerate(order):
+            tri[i0 + j] = base + np.array([0.0, 0.0, -0.15 * dz])
+        if s % 3 == 0:
+            tri[i0 + 5] = tri[i0 + 4]                                    # coincident pair: order decides
+    prims["v"] = tri.reshape(n, 9)
+    mats = np.zeros(3, _MAT_DT); mats["type"] = [0, 1, 2]; mats["albedo"] = rng.uniform(0.2, 1.0, size=(3, 3)); mats["param"] = [0, 0.4, 1.5]
+    prims["material"] = rng.integers(0, 3, size=n)
+    cent = ((tri[:, 0] + tri[:, 1]) + tri[:, 2]) / 3.0
+    return HittableList.from_arrays(prims, cent, mats, filename="scenes/soup.json")
+
+
+@pytest.mark.parametrize("seed,n,spread,grid_size,center", [(1, 64, 0.8, 25.0, (10.0, 10.0, -12.0)), (2, 65, 0.8, 25.0, (10.0, 10.0, -12.0)),
+                                                            (3, 128, 1.0, 25.0, (10.0, 10.0, -12.0)), (4, 700, 3.0, 25.0, (0.0, 0.0, -6.0)),
+                                                            (5, 1500, 6.0, 5.0, (0.0, 0.0, -6.0)), (6, 3000, 9.0, 5.0, (0.0, 0.0, -6.0)),
+                                                            (7, 129, 0.5, 5.0, (2.5, 2.5, -7.5))])
+def test_cooperative_grid_cells_bit_exact(gpu, monkeypatch, seed, n, spread, grid_size, center):
+    """The wave-cooperative cell test against the oracle's literal GridBox::hit: list lengths on both sides of the chunk size,
+    several acceptances inside one chunk, clobbered rec.t / rec.p from failed tests (triangle.rs:52,59), rays of a wave in different
+    cells (groups of one) and in the same cell (groups of 64), degenerate rays; traces, counters and a rendered image.
+    RT_GRID_COOP_SHARE=0 / RT_GRID_COOP_MIN=64 make every grid with a cell of >= 64 triangles take the cooperative kernel (the
+    defaults want lists of >= 128 holding half of all entries)."""
+    import raytracer_amd as rt
+    w = _triangle_soup(seed, n, spread, stacked=max(2, n // 60), center=center)
+    osc = setup_pair(w, "grid", "sah-position", grid_size)
+    ln = np.diff(w.grid.cell_offset().astype(np.int64))
+    assert (ln >= 64).any(), "no cell of this scene is chunked: the test would not reach the cooperative path"
+    if seed in (1, 2):
+        assert ln.max() == n, "the whole soup was meant to sit in one cell"
+    try:
+        monkeypatch.setenv("RT_GRID_COOP_SHARE", "0"); monkeypatch.setenv("RT_GRID_COOP_MIN", "64"); rt.init(0)
+        w.upload()
+    finally:
+        monkeypatch.delenv("RT_GRID_COOP_SHARE"); monkeypatch.delenv("RT_GRID_COOP_MIN"); rt.init(0)
+    ctr = np.array(center)
+    rng = np.random.default_rng(seed)
+    # rays through the stacks and the crowd, from both sides; coherent bundles (one origin, a fan of directions) and scattered ones
+    o1 = np.tile(ctr + np.array([[0.0, 0.0, 8.0]]), (4096, 1)); d1 = np.array([0.0, 0.0, -1.0]) + rng.normal(scale=0.35, size=(4096, 3))
+    o2 = rng.uniform(-8, 8, size=(6000, 3)) + ctr; d2 = rng.normal(size=(6000, 3))
+    o3, d3 = _edge_rays(w, 2000, seed + 40)
+    o = np.concatenate([o1, o2, o3]); d = np.concatenate([d1, d2, d3])
+    with np.errstate(all="ignore"):
+        assert_trace_equal(w.hit(o, d), osc.trace("grid", o, d), f"soup {seed}: tmax inf")
+        assert_trace_equal(w.hit(o, d, 0.001, 3.0), osc.trace("grid", o, d, 0.001, 3.0), f"soup {seed}: tmax 3")
+    cam = Camera(w.filename, image_width=96, samples_per_pixel=4, max_depth=10)
+    img, st = cam.render(w, seed=seed)
+    ref, cst = osc.render(O.camera_from_rt(cam.c), "grid", 0, 4, 10, seed=seed, nthreads=8)
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "gridbox_intersection_checks"):
+        assert st[k] == cst[k], f"soup {seed}: counter {k}: gpu {st[k]} oracle {cst[k]}"
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(img), fin)
+    assert np.max(np.abs(img[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300), initial=0.0) <= RADIANCE_RTOL
+    w.close()
