@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo is for rehearsing N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline duration")
+    ap.add_argument("--reduce", default="torch", choices=["torch", "product"],
+                    help="the per-step framebuffer reduce: torch.distributed.reduce (RCCL through torch; default) or the product library's own "
+                         "communicator (rt_comm_reduce_sum = ncclReduce; also exercised at N = 1)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that feed the roofline")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the profiled re-run: one step, counters only
     return ap.parse_args()
@@ -133,9 +136,19 @@ def main():
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"))
     torch.cuda.synchronize()
 
+    comm = None
+    if a.reduce == "product":                                 # the library's own RCCL communicator (include/rt_hip.h rt_comm_*)
+        ids = [rt.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = rt.Comm(ids[0], world, rank)
+
     def step():
         _, st = cam.render(w, seed=1, s_begin=s_begin, s_count=s_count, d_out=fb.data_ptr(), stream=stream)
-        reduce_framebuffer(fb, dst=0)                        # RCCL over xGMI: the one exchange step of the path
+        if comm is not None:
+            comm.reduce_sum(fb.data_ptr(), fb.numel(), root=0, stream=stream)
+        else:
+            reduce_framebuffer(fb, dst=0)                    # RCCL over xGMI: the one exchange step of the path
         return st
 
     def fence():
@@ -193,7 +206,8 @@ def main():
             "config": {"workload": f"{label}; --algorithm {'bvh (SAH position)' if a.algorithm == 'bvh' else a.algorithm + (f' size={a.grid_size:g}' if a.algorithm == 'grid' else '')}; {W}x{H}; {a.spp_per_gpu} spp per GPU "
                                    f"({a.spp_per_gpu * world} spp total, spp-split); max_depth {a.max_depth}; camera preset dragon/0",
                        "primitives": len(w), "bvh_nodes": w.bvh.n_nodes if w.bvh else None, "bvh_depth": w.bvh.depth if w.bvh else None,
-                       "parallelism": f"spp-split x{world}, replicated scene, one RCCL reduce of the f64 framebuffer per step ({world} ranks)" if world > 1 else "single GPU",
+                       "parallelism": (f"spp-split x{world}, replicated scene, one RCCL reduce of the f64 framebuffer per step ({world} ranks, "
+                                       f"{'rt_comm_reduce_sum of the product library' if a.reduce == 'product' else 'torch.distributed.reduce'})") if world > 1 else "single GPU",
                        "init_seconds_excluded": round(init_s, 2)},
             "rays_per_step": total_rays / a.steps,
             "kernel_ms_per_step": {k: prof[k] for k in ("generate_ms", "extend_ms", "shade_ms", "resolve_ms")},

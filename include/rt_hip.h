@@ -166,6 +166,27 @@ int rt_render_device_noalloc(rt_scene*, const rt_camera*, int algorithm, uint32_
  * sizes still resize the workspace themselves. */
 int rt_scene_reserve(rt_scene*, uint32_t image_width, uint32_t image_height, uint32_t s_count, uint32_t max_depth);
 
+/* ---- multi-GPU: the one exchange step of the path.  No counterpart in the reference (single process, CPU).
+ * Samples are split over ranks, one process per GPU, every rank renders its global sample indices of every pixel with a
+ * replicated scene; the W*H*3 f64 framebuffers are then summed to one rank with ONE RCCL ncclReduce(sum) over xGMI.
+ * librccl is opened with dlopen on first use (no link-time dependency): without it these calls return RT_E_STATE.
+ *   rt_comm_unique_id   ncclGetUniqueId: rank 0 calls it and hands the RT_COMM_ID_BYTES to the other ranks by any means
+ *                       (the CLI uses a shared mapping, a launcher its own store)
+ *   rt_comm_create      ncclCommInitRank on the device of rt_init(); collective over the n_ranks processes
+ *   rt_comm_reduce_sum  in-place ncclReduce(ncclDouble, ncclSum) of `count` doubles at d_buf to `root`, enqueued on `stream`
+ *                       (NULL: the library's stream) and waited for; on the other ranks d_buf is left unspecified
+ *   rt_render_reduce    rt_render_device into a library-owned device framebuffer + rt_comm_reduce_sum + (root only) the
+ *                       copy to the host array out_sum (W*H*3; may be NULL on the other ranks).  Counters are per rank.
+ * One GPU can belong to a communicator only once: ranks that share a GPU (rehearsals) cannot use these calls. */
+typedef struct rt_comm rt_comm;
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void* id_out);
+int rt_comm_create(const void* id, int n_ranks, int rank, rt_comm** out);
+int rt_comm_reduce_sum(rt_comm*, double* d_buf, uint64_t count, int root, void* stream);
+int rt_comm_destroy(rt_comm*);
+int rt_render_reduce(rt_scene*, const rt_camera*, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                     uint64_t seed, rt_comm*, int root, double* out_sum, rt_stats* stats);
+
 /* Replaces dropping the HittableList. */
 void rt_scene_destroy(rt_scene*);
 

@@ -58,9 +58,12 @@ class RtStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+RT_COMM_ID_BYTES = 128
+
 # every symbol include/rt_hip.h declares (tests check the library exports exactly these)
 RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_scene_build_grid", "rt_scene_get_grid", "rt_trace",
-                  "rt_generate", "rt_render", "rt_render_device", "rt_render_device_noalloc", "rt_scene_reserve", "rt_scene_destroy", "rt_last_error"]
+                  "rt_generate", "rt_render", "rt_render_device", "rt_render_device_noalloc", "rt_scene_reserve", "rt_scene_destroy", "rt_last_error",
+                  "rt_comm_unique_id", "rt_comm_create", "rt_comm_reduce_sum", "rt_comm_destroy", "rt_render_reduce"]
 
 _hip = None
 _host = None
@@ -107,6 +110,12 @@ def hip_lib():
     lib.rt_scene_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]; lib.rt_scene_reserve.restype = C.c_int
     lib.rt_scene_destroy.argtypes = [C.c_void_p]; lib.rt_scene_destroy.restype = None
     lib.rt_last_error.argtypes = []; lib.rt_last_error.restype = C.c_char_p
+    lib.rt_comm_unique_id.argtypes = [C.c_void_p]; lib.rt_comm_unique_id.restype = C.c_int
+    lib.rt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]; lib.rt_comm_create.restype = C.c_int
+    lib.rt_comm_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]; lib.rt_comm_reduce_sum.restype = C.c_int
+    lib.rt_comm_destroy.argtypes = [C.c_void_p]; lib.rt_comm_destroy.restype = C.c_int
+    lib.rt_render_reduce.argtypes = [C.c_void_p, P(RtCamera), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, P(RtStats)]
+    lib.rt_render_reduce.restype = C.c_int
     _hip = lib
     return lib
 

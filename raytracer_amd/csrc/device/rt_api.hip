@@ -3,6 +3,9 @@
 #include "rt_kernels.hip"
 #include "../../../include/rt_hip.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>       // types and enums only: the functions are looked up with dlsym (rt_comm_*)
+
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -919,6 +922,97 @@ int rt_render_device_noalloc(rt_scene* sc, const rt_camera* cam, int algorithm, 
     // every queue, counter and record of the array that a batch reads is written by that batch first (counts and stats are
     // cleared by render_impl); nothing is kept between calls
     return render_impl(sc, w, (uint32_t)k64, cam, algorithm, s_begin, s_count, max_depth, seed, d_out_sum, stream ? (hipStream_t)stream : g_stream, stats);
+}
+
+// ---- RCCL: ncclReduce(sum, root) of the framebuffers over xGMI.  The library is opened on first use.
+struct rt_comm { ncclComm_t comm = nullptr; int n_ranks = 0, rank = 0, device = -1; };
+namespace {
+struct Rccl {
+    void* lib = nullptr; bool tried = false; std::string err;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr; decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclReduce) reduce = nullptr; decltype(&ncclCommDestroy) comm_destroy = nullptr; decltype(&ncclGetErrorString) error_string = nullptr;
+} g_rccl;
+int rccl_load() {
+    if (g_rccl.tried) return g_rccl.lib ? RT_OK : fail(RT_E_STATE, "RCCL is not available: %s", g_rccl.err.c_str());
+    g_rccl.tried = true;
+    const char* names[] = {getenv("RT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) { if (!nm || !*nm) continue; g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; g_rccl.err = dlerror(); }
+    if (!g_rccl.lib) return fail(RT_E_STATE, "RCCL is not available: %s", g_rccl.err.c_str());
+    g_rccl.get_unique_id = (decltype(g_rccl.get_unique_id))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.reduce = (decltype(g_rccl.reduce))dlsym(g_rccl.lib, "ncclReduce");
+    g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.error_string = (decltype(g_rccl.error_string))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.reduce || !g_rccl.comm_destroy || !g_rccl.error_string) {
+        g_rccl.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclReduce / ncclCommDestroy / ncclGetErrorString";
+        dlclose(g_rccl.lib); g_rccl.lib = nullptr;
+        return fail(RT_E_STATE, "RCCL is not available: %s", g_rccl.err.c_str());
+    }
+    return RT_OK;
+}
+#define RCCLCHECK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(RT_E_HIP, "%s failed: %s", #x, g_rccl.error_string(r_)); } while (0)
+} // namespace
+
+int rt_comm_unique_id(void* id_out) {
+    static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "RT_COMM_ID_BYTES must be the size of ncclUniqueId");
+    if (!id_out) return fail(RT_E_ARG, "null argument");
+    { const int rc = rccl_load(); if (rc) return rc; }
+    ncclUniqueId id;
+    RCCLCHECK(g_rccl.get_unique_id(&id));
+    memcpy(id_out, &id, sizeof id);
+    return RT_OK;
+}
+
+int rt_comm_create(const void* id, int n_ranks, int rank, rt_comm** out) {
+    if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
+    if (!id || !out) return fail(RT_E_ARG, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RT_E_ARG, "rank %d of %d", rank, n_ranks);
+    { const int rc = rccl_load(); if (rc) return rc; }
+    HIPCHECK(hipSetDevice(g_device));
+    ncclUniqueId uid; memcpy(&uid, id, sizeof uid);
+    ncclComm_t c = nullptr;
+    RCCLCHECK(g_rccl.comm_init_rank(&c, n_ranks, uid, rank));
+    rt_comm* rc = new rt_comm(); rc->comm = c; rc->n_ranks = n_ranks; rc->rank = rank; rc->device = g_device;
+    *out = rc;
+    return RT_OK;
+}
+
+int rt_comm_reduce_sum(rt_comm* c, double* d_buf, uint64_t count, int root, void* stream) {
+    if (!c || !c->comm || (count && !d_buf)) return fail(RT_E_ARG, "null argument");
+    if (root < 0 || root >= c->n_ranks) return fail(RT_E_ARG, "root %d of %d ranks", root, c->n_ranks);
+    if (c->device != g_device) return fail(RT_E_STATE, "the communicator was created on device %d, the current device is %d", c->device, g_device);
+    hipStream_t st = stream ? (hipStream_t)stream : g_stream;
+    if (count) RCCLCHECK(g_rccl.reduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, root, c->comm, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_comm_destroy(rt_comm* c) {
+    if (!c) return RT_OK;
+    int ret = RT_OK;
+    if (c->comm && g_rccl.comm_destroy) { ncclResult_t r = g_rccl.comm_destroy(c->comm); if (r != ncclSuccess) ret = fail(RT_E_HIP, "ncclCommDestroy failed: %s", g_rccl.error_string(r)); }
+    delete c;
+    return ret;
+}
+
+int rt_render_reduce(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,
+                     uint64_t seed, rt_comm* c, int root, double* out_sum, rt_stats* stats) {
+    if (!cam || !c) return fail(RT_E_ARG, "null argument");
+    if (root < 0 || root >= c->n_ranks) return fail(RT_E_ARG, "root %d of %d ranks", root, c->n_ranks);
+    if (c->rank == root && !out_sum) return fail(RT_E_ARG, "the root rank needs out_sum");
+    const uint64_t WH = (uint64_t)cam->image_width * cam->image_height;
+    double* d_fb = nullptr;
+    HIPCHECK(hipMalloc(&d_fb, (WH ? WH : 1) * 3 * sizeof(double)));
+    int rc = render_dynamic(sc, cam, algorithm, s_begin, s_count, max_depth, seed, d_fb, g_stream, stats);
+    // every rank takes part in the reduce even if its render failed?  No: a failed rank returns, and its peers' reduce would wait
+    // for it — the caller must treat any rank's error as fatal for the job (the CLI kills its workers)
+    if (rc == RT_OK) rc = rt_comm_reduce_sum(c, d_fb, WH * 3, root, g_stream);
+    if (rc == RT_OK && c->rank == root) {
+        hipError_t e = hipMemcpy(out_sum, d_fb, WH * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_E_HIP, "framebuffer readback failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_fb);
+    return rc;
 }
 
 int rt_render(rt_scene* sc, const rt_camera* cam, int algorithm, uint32_t s_begin, uint32_t s_count, uint32_t max_depth,

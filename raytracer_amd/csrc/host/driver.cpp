@@ -34,6 +34,9 @@ static const char* kHelp =
     "      --device <N>             GPU index [default: 0] (addition)\n"
     "      --gpus <N>               Split the samples over N GPUs, one forked worker process each, partial sums added in rank\n"
     "                               order (addition; with an explicit --device every worker uses that GPU: rehearsal) [default: 1]\n"
+    "      --reduce <HOW>           How --gpus sums the workers' framebuffers: rccl = one ncclReduce(sum) to worker 0 over xGMI,\n"
+    "                               host = the parent adds partial sums from shared memory; auto = rccl when every worker has its own\n"
+    "                               GPU [default: auto] [possible values: auto, rccl, host]\n"
     "      --subdivide <L>          Split every PLY triangle into 4, L times (addition; synthetic meshes)\n"
     "      --output-dir <DIR>       Where the .ppm and stats.csv go [default: output]\n"
     "  -h, --help                   Print help\n";
@@ -67,6 +70,7 @@ bool parse_cli(int argc, const char* const* argv, Cli& out, std::string& err) {
         else if (key == "--seed") { if (!need(i, "--seed", v)) return false; out.seed = strtoull(v.c_str(), nullptr, 10); }
         else if (key == "--device") { if (!need(i, "--device", v)) return false; out.device = atoi(v.c_str()); out.device_given = true; }
         else if (key == "--gpus") { if (!need(i, "--gpus", v)) return false; out.gpus = atoi(v.c_str()); if (out.gpus < 1 || out.gpus > 64) { err = "error: --gpus must be in 1..64"; return false; } }
+        else if (key == "--reduce") { if (!need(i, "--reduce", v)) return false; if (v == "auto") out.reduce = 0; else if (v == "rccl") out.reduce = 1; else if (v == "host") out.reduce = 2; else { err = "error: invalid value '" + v + "' for '--reduce <HOW>' [possible values: auto, rccl, host]"; return false; } }
         else if (key == "--subdivide") { if (!need(i, "--subdivide", v)) return false; out.subdivide = atoi(v.c_str()); if (out.subdivide < 0 || out.subdivide > 4) { err = "error: --subdivide must be in 0..4"; return false; } }
         else if (key == "--binary-ppm") out.binary_ppm = true;
         else if (key == "--gpu-build") out.gpu_build = true;
@@ -166,8 +170,11 @@ struct Accel { bool have_bvh = false, have_grid = false; Bvh bvh; Grid grid; };
 
 // The device part of world.init() + cam.render() for samples [s_begin, s_begin + s_count) on one GPU: upload, flatten (or
 // build on the GPU with --gpu-build), rt_render.  `sum` receives W*H*3 partial sums.
+// With `comm_id` (rt_comm_unique_id bytes, RCCL path): the rank joins an n_ranks communicator and rt_render_reduce sums the
+// framebuffers onto rank 0 with one ncclReduce; only rank 0's `sum` is written.
 int render_slice(const Cli& cli, const Scene& scene, const Accel& acc, const rt_camera& rc, uint32_t max_depth, bool draw_boxes, int device,
-                 uint32_t s_begin, uint32_t s_count, double* sum, rt_stats* st, double* init_seconds, std::string& err) {
+                 uint32_t s_begin, uint32_t s_count, double* sum, rt_stats* st, double* init_seconds, std::string& err,
+                 const void* comm_id = nullptr, int n_ranks = 1, int rank = 0) {
     if (rt_init(device) != RT_OK) { err = rt_last_error(); return 3; }
     // init_time covers world.init() (main.rs:126-129): upload + flatten / GPU build, not HIP start-up (context, code object)
     auto start = std::chrono::steady_clock::now();
@@ -199,7 +206,12 @@ int render_slice(const Cli& cli, const Scene& scene, const Accel& acc, const rt_
         }
     }
     *init_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
-    if (rt_render(dev, &rc, cli.algorithm, s_begin, s_count, max_depth, cli.seed, sum, st) != RT_OK) return fail_hip();
+    if (comm_id) {
+        rt_comm* comm = nullptr;
+        if (rt_comm_create(comm_id, n_ranks, rank, &comm) != RT_OK) return fail_hip();
+        if (rt_render_reduce(dev, &rc, cli.algorithm, s_begin, s_count, max_depth, cli.seed, comm, 0, rank == 0 ? sum : nullptr, st) != RT_OK) { err = rt_last_error(); rt_comm_destroy(comm); rt_scene_destroy(dev); return 3; }
+        rt_comm_destroy(comm);
+    } else if (rt_render(dev, &rc, cli.algorithm, s_begin, s_count, max_depth, cli.seed, sum, st) != RT_OK) return fail_hip();
     rt_scene_destroy(dev);
     return 0;
 }
@@ -269,22 +281,31 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     const uint64_t n_pixels = (uint64_t)rc.image_width * rc.image_height;
     std::vector<double> sum(n_pixels * 3);
     rt_stats st; memset(&st, 0, sizeof st);
-    if (cli.gpus <= 1) {
+    // --reduce: rccl needs one GPU per worker; an explicit --device puts every worker on that GPU (rehearsal) -> host sums
+    const bool distinct_gpus = !(cli.device_given && cli.gpus > 1);
+    if (cli.reduce == 1 && !distinct_gpus) { err = "--reduce rccl needs one GPU per worker: a communicator cannot hold the same GPU twice (drop --device, or use --reduce host)"; return 2; }
+    const bool use_rccl = cli.reduce == 1 || (cli.reduce == 0 && cli.gpus > 1 && distinct_gpus);
+    if (cli.gpus <= 1 && !use_rccl) {
         double dev_init = 0;
         const int rcode = render_slice(cli, scene, acc, rc, cam.max_depth, draw_boxes, cli.device, 0, cam.samples_per_pixel, sum.data(), &st, &dev_init, err);
         if (rcode) return rcode;
         rs.init_time = host_init + dev_init;
     } else {
         // SURVEY 8(e) without a launcher: one worker process per GPU, forked BEFORE anything touches HIP (a forked copy of a
-        // process that has initialised the GPU is not usable), each rendering its own global sample indices of every pixel
-        // into shared memory; the parent adds the partial sums in rank order (fixed association: reproducible for a given N).
+        // process that has initialised the GPU is not usable), each rendering its own global sample indices of every pixel.
+        //   rccl: worker 0 draws the communicator id and publishes it in the shared mapping; every worker joins, renders into its
+        //         device framebuffer and takes part in ONE ncclReduce(sum, root 0) (rt_render_reduce); worker 0 writes the sum.
+        //   host: every worker writes its partial sums into the mapping; the parent adds them in rank order.
         const uint32_t N = (uint32_t)cli.gpus;
         struct Slot { int rc; double dev_init; rt_stats st; char err[480]; };
+        struct Shared { volatile int id_ready; char id[RT_COMM_ID_BYTES]; };
         const size_t fb_bytes = (size_t)n_pixels * 3 * sizeof(double);
-        const size_t total = (size_t)N * fb_bytes + (size_t)N * sizeof(Slot);
+        const size_t n_fb = use_rccl ? 1 : N;
+        const size_t total = n_fb * fb_bytes + (size_t)N * sizeof(Slot) + sizeof(Shared);
         void* shm = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
         if (shm == MAP_FAILED) { err = "mmap of the shared framebuffers failed"; return 1; }
-        Slot* slots = (Slot*)((char*)shm + (size_t)N * fb_bytes);
+        Slot* slots = (Slot*)((char*)shm + n_fb * fb_bytes);
+        Shared* shared = (Shared*)((char*)slots + (size_t)N * sizeof(Slot));
         fflush(stdout); fflush(stderr);
         std::vector<pid_t> pids(N, -1);
         for (uint32_t g = 0; g < N; ++g) {
@@ -293,28 +314,57 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
             if (pid < 0) { err = "fork failed"; for (uint32_t k = 0; k < g; ++k) { kill(pids[k], SIGKILL); waitpid(pids[k], nullptr, 0); } munmap(shm, total); return 1; }
             if (pid == 0) {
                 std::string werr; Slot& sl = slots[g];
-                sl.rc = render_slice(cli, scene, acc, rc, cam.max_depth, draw_boxes, cli.device_given ? cli.device : (int)g, sb, scount,
-                                     (double*)((char*)shm + (size_t)g * fb_bytes), &sl.st, &sl.dev_init, werr);
+                const int dev = cli.device_given ? cli.device : (int)g;
+                if (use_rccl) {
+                    sl.rc = 0;
+                    if (g == 0) {                              // rank 0 draws the id after ITS rt_init (nothing touched HIP before the fork)
+                        if (rt_init(dev) != RT_OK || rt_comm_unique_id(shared->id) != RT_OK) { werr = rt_last_error(); sl.rc = 3; }
+                        __sync_synchronize(); shared->id_ready = sl.rc ? -1 : 1;
+                    } else {
+                        while (shared->id_ready == 0) usleep(1000);
+                        __sync_synchronize();
+                        if (shared->id_ready < 0) { werr = "rank 0 could not create the communicator id"; sl.rc = 3; }
+                    }
+                    if (!sl.rc) sl.rc = render_slice(cli, scene, acc, rc, cam.max_depth, draw_boxes, dev, sb, scount, (double*)shm, &sl.st, &sl.dev_init, werr, shared->id, (int)N, (int)g);
+                } else {
+                    sl.rc = render_slice(cli, scene, acc, rc, cam.max_depth, draw_boxes, dev, sb, scount,
+                                         (double*)((char*)shm + (size_t)g * fb_bytes), &sl.st, &sl.dev_init, werr);
+                }
                 snprintf(sl.err, sizeof sl.err, "%s", werr.c_str());
                 fflush(stderr);
                 _exit(sl.rc ? 1 : 0);                 // no static destructors of the parent's copy
             }
             pids[g] = pid;
         }
-        int bad = 0;
-        for (uint32_t g = 0; g < N; ++g) {
-            int status = 0;
-            if (waitpid(pids[g], &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
-                if (!bad) err = "worker " + std::to_string(g) + ": " + ((WIFEXITED(status) && slots[g].err[0]) ? std::string(slots[g].err) : std::string("ended abnormally"));
-                bad = 3;
+        // wait for all workers; the first failure ends the others (a rank that died would leave its peers waiting in the
+        // communicator's rendezvous or in the reduce for ever)
+        int bad = 0; uint32_t left = N;
+        std::vector<bool> done(N, false);
+        while (left) {
+            bool progressed = false;
+            for (uint32_t g = 0; g < N; ++g) {
+                if (done[g]) continue;
+                int status = 0;
+                const pid_t w = waitpid(pids[g], &status, WNOHANG);
+                if (w == 0) continue;
+                done[g] = true; --left; progressed = true;
+                if (w < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+                    if (!bad) err = "worker " + std::to_string(g) + ": " + ((w > 0 && WIFEXITED(status) && slots[g].err[0]) ? std::string(slots[g].err) : std::string("ended abnormally"));
+                    bad = 3;
+                    for (uint32_t k = 0; k < N; ++k) if (!done[k]) kill(pids[k], SIGKILL);
+                }
             }
+            if (!progressed) usleep(2000);
         }
         if (bad) { munmap(shm, total); return bad; }
         double dev_init = 0;
         for (uint32_t g = 0; g < N; ++g) {
-            const double* part = (const double*)((const char*)shm + (size_t)g * fb_bytes);
-            if (g == 0) memcpy(sum.data(), part, fb_bytes);
-            else for (size_t i = 0; i < sum.size(); ++i) sum[i] = sum[i] + part[i];
+            if (use_rccl) { if (g == 0) memcpy(sum.data(), shm, fb_bytes); }        // already summed on the GPUs, rank 0 wrote it
+            else {
+                const double* part = (const double*)((const char*)shm + (size_t)g * fb_bytes);
+                if (g == 0) memcpy(sum.data(), part, fb_bytes);
+                else for (size_t i = 0; i < sum.size(); ++i) sum[i] = sum[i] + part[i];
+            }
             const rt_stats& w = slots[g].st;
             st.primary_rays += w.primary_rays; st.scatter_rays += w.scatter_rays; st.intersection_checks += w.intersection_checks;
             st.traversal_steps += w.traversal_steps; st.overlapping_aabb += w.overlapping_aabb; st.gridbox_intersection_checks += w.gridbox_intersection_checks;
@@ -323,6 +373,7 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
         }
         munmap(shm, total);
         rs.init_time = host_init + dev_init;
+        fprintf(stderr, "%u worker%s, framebuffers summed %s\n", N, N == 1 ? "" : "s", use_rccl ? "with one RCCL ncclReduce (sum, root 0)" : "by the parent from shared memory");
     }
     std::vector<uint8_t> rgb(n_pixels * 3);
     resolve_pixels(sum.data(), n_pixels, cam.samples_per_pixel, rgb.data());

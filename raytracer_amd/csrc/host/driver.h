@@ -24,6 +24,9 @@ struct Cli {                                                                // r
     uint64_t seed = 1;
     int device = 0; bool device_given = false;
     int gpus = 1;                       // --gpus N: spp-split over N forked workers, one GPU each; CLI binary only
+    int reduce = 0;                     // --reduce auto|rccl|host (0/1/2): how the workers' framebuffers are summed.  rccl = one ncclReduce(sum, root 0)
+                                        // over xGMI (rt_render_reduce); host = partial sums added by the parent through shared memory.  auto = rccl when
+                                        // N > 1 and every worker has a GPU of its own, host otherwise (workers sharing one GPU cannot form a communicator)
     int subdivide = 0;                  // synthetic refinement levels for PLY meshes (not a reference feature)
     std::string output_dir = "output";
     bool gpu_build = false;             // --gpu-build: Bvh::new (default SAH mode) / Grid::new on the GPU

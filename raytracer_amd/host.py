@@ -304,6 +304,49 @@ class Camera:
         return rgb
 
 
+class Comm:
+    """RCCL communicator of the product library (rt_comm_*, include/rt_hip.h): the spp-split's one exchange step,
+    ncclReduce(sum, root) of the f64 framebuffers.  `unique_id()` on rank 0, hand the bytes to the other ranks, then every rank
+    constructs Comm(id, n_ranks, rank) — a collective call."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(F.RT_COMM_ID_BYTES)
+        _hip_check(F.hip_lib().rt_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, n_ranks, rank):
+        if len(uid) != F.RT_COMM_ID_BYTES:
+            raise RtError(f"a communicator id has {F.RT_COMM_ID_BYTES} bytes")
+        h = C.c_void_p()
+        _hip_check(F.hip_lib().rt_comm_create(uid, int(n_ranks), int(rank), C.byref(h)))
+        self._h, self.n_ranks, self.rank = h, int(n_ranks), int(rank)
+
+    def reduce_sum(self, d_ptr, count, root=0, stream=None):
+        """In-place sum of `count` doubles at device pointer `d_ptr` onto rank `root`; returns when the reduce has finished."""
+        _hip_check(F.hip_lib().rt_comm_reduce_sum(self._h, C.c_void_p(d_ptr), int(count), int(root), C.c_void_p(stream or 0)))
+
+    def render_reduce(self, cam, world, seed=1, s_begin=0, s_count=None, root=0):
+        """rt_render_reduce: this rank's samples, then the reduce; the root gets the summed image, the others None."""
+        s_count = cam.samples_per_pixel if s_count is None else s_count
+        out = np.empty((cam.image_height, cam.image_width, 3), np.float64) if self.rank == root else None
+        st = F.RtStats()
+        _hip_check(F.hip_lib().rt_render_reduce(world._dev, C.byref(cam.c), world.ALGOS[world.algorithm], s_begin, s_count, cam.max_depth, seed,
+                                                self._h, int(root), out.ctypes.data if out is not None else None, C.byref(st)))
+        return out, st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            F.hip_lib().rt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run(argv):
     """run(Cli) (src/main.rs:31-140): argv as the reference binary takes it, e.g.
     ``run(["scenes/weekend-final.json", "--algorithm", "bvh"])``.  Returns the exit code."""

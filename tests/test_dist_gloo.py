@@ -81,27 +81,39 @@ def test_bench_gpus_flag_starts_that_many_ranks(monkeypatch):
         bench.main()
 
 
-def test_multi_gpu_bench_line_reuses_the_committed_single_gpu_counters():
+def test_multi_gpu_bench_line_reuses_the_committed_single_gpu_counters(tmp_path):
     """N > 1 cannot run the profiler passes; rank 0 traces the paths of the N = 1 run, so bench.py prices its own times with the
-    committed N = 1 counters when the per-GPU workload is the same, and with nothing otherwise."""
+    committed N = 1 counters when the per-GPU workload AND the device sources (by hash) are the same — flagged measured = false —
+    and with nothing otherwise (a kernel change must not silently report a stale VALU fraction)."""
     import importlib.util
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    ref = json.load(open(os.path.join(root, "profiles", "round2_bench.json")))
+    ref = json.load(open(os.path.join(root, "profiles", "round2_bench.json")))     # a real N = 1 line (round 2's; it carries no hash)
+    ref["source_hash"] = bench.source_hash()
+    line = tmp_path / "committed.json"; line.write_text(json.dumps(ref))
+    bench.COMMITTED_LINE = str(line)
 
     class A:
         spp_per_gpu, max_depth = 128, 50
     wl8 = ref["config"]["workload"].replace("(128 spp total", "(1024 spp total")
     p = bench.committed_pmc(wl8, 8, A)
-    assert p and "committed N = 1 run" in p["source"] and p["child"]["segments"] == ref["roofline"]["pmc"]["segments_profiled"]
+    assert p and p["committed"] and "committed N = 1 run" in p["source"] and p["child"]["segments"] == ref["roofline"]["pmc"]["segments_profiled"]
     r = ref["roofline"]
     seg = p["child"]["segments"]
     c = {"segments": seg, "box_tests": int(r["box_tests_per_segment"] * seg), "prim_tests": int(r["prim_tests_per_segment"] * seg),
          "launches": 45, "extend_s": r["avg_launch_ms"] * 45 / 1e3, "pair_bytes": 64, "prim_bytes": 48}
     rr = bench.roofline(c, p)
-    assert rr["bound"] == "valu" and abs(rr["frac"] - r["frac"]) < 0.01 and 0 < rr["hbm"]["frac"] < 1
+    assert rr["bound"] == "valu" and rr["measured"] is False and abs(rr["frac"] - r["frac"]) < 0.01 and 0 < rr["hbm"]["frac"] < 1
     A.spp_per_gpu = 64
     assert bench.committed_pmc(wl8, 8, A) is None
-    assert bench.roofline(c, None)["bound"] == "l1_lane_access"
+    A.spp_per_gpu = 128
+    ref["source_hash"] = "0" * 16; line.write_text(json.dumps(ref))        # counters of other kernels: not used
+    assert bench.committed_pmc(wl8, 8, A) is None
+    rr = bench.roofline(c, None)
+    assert rr["bound"] == "l1_lane_access" and rr["measured"] is True
+    # the line the repository commits for this round, when present, is one bench.py can read
+    if os.path.exists(os.path.join(root, "profiles", "round3_bench.json")):
+        cur = json.load(open(os.path.join(root, "profiles", "round3_bench.json")))
+        assert "source_hash" in cur and "counters" in cur["roofline"]["pmc"]
