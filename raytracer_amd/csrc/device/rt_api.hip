@@ -67,6 +67,8 @@ bool g_cell_tri = true;               // RT_CELL_TRI=0: the grid walk reads list
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 uint32_t g_grid_coop_share_num = 1, g_grid_coop_share_den = 2;   // ... and only if such cells hold at least this share of all list entries (RT_GRID_COOP_SHARE, percent)
 uint32_t g_grid_coop_min = 128;       // RT_GRID_COOP_MIN: cells whose list has at least this many triangles are tested by the whole wave (k_extend_grid_coop); 0 = never
+int g_shade_mode = 3;                 // RT_SHADE_MODE bit 0: prefetch the next tile's queue entry; bit 1: 48-byte spheres in shade (k_shade<MODE>).  Both on:
+                                      // weekend-final shade 58.3 -> 53.4 ms (profiles/round3_shade_variants.md); RT_SHADE_MODE=0 is the round-2 kernel
 bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
                                       // measured 8.5 % slower on the headline workload (profiles/round3_extend_variants.md), kept for the A/B
 
@@ -219,11 +221,11 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         // with nearly empty cells (size 1) the second array only costs cache (+5 %)
         const DTriPre* gpre = (sc->grid_list_len * 10ull >= sc->grid.n_cells) ? sc->d_tri_pre : nullptr;
         if (sc->draw_boxes)
-            hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, d_stats);
+            hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
         else if (sc->n_chunks && sc->d_tri_pre)          // some cells are well filled: the whole wave tests their lists (all-triangle scenes)
-            hipLaunchKernelGGL(k_extend_grid_coop, grid, block, 0, st, sc->grid, sc->d_prims, sc->d_tri_pre, in, count, n_fixed, tmin, tmax, out, d_stats);
+            hipLaunchKernelGGL(k_extend_grid_coop, grid, block, 0, st, sc->grid, sc->d_prims, sc->d_tri_pre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
         else
-            hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, d_stats);
+            hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
         break;
     }
     default:
@@ -332,8 +334,13 @@ int render_impl(rt_scene* sc, Workspace& w, uint32_t k, const rt_camera* cam, in
             if (rc) return rc;
             end_span();
             begin_span(K_SHADE);
-            hipLaunchKernelGGL(k_shade, sgrid, block, 0, st, sprims, sc->d_mats, sc->n_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr,
-                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, kb, b, max_depth, seed, w.stats);
+            {
+                const DSphere* sph = (algorithm == RT_ALGO_BVH && (g_shade_mode & 2)) ? sc->d_spheres : nullptr;     // BVH order, like sprims
+#define RT_LAUNCH_SHADE(M) hipLaunchKernelGGL(k_shade<M>, sgrid, block, 0, st, sprims, sph, sc->d_mats, sc->n_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr, \
+                               w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, kb, b, max_depth, seed, w.stats)
+                switch (g_shade_mode & 3) { case 1: RT_LAUNCH_SHADE(1); break; case 2: RT_LAUNCH_SHADE(2); break; case 3: RT_LAUNCH_SHADE(3); break; default: RT_LAUNCH_SHADE(0); }
+#undef RT_LAUNCH_SHADE
+            }
             end_span();
             ++launched;
             if (!readback) continue;
@@ -441,6 +448,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
+    g_shade_mode = 3; if (const char* s = getenv("RT_SHADE_MODE")) g_shade_mode = atoi(s) & 3;
     g_grid_coop_min = 128; if (const char* s = getenv("RT_GRID_COOP_MIN")) g_grid_coop_min = (uint32_t)strtoul(s, nullptr, 10);
     g_grid_coop_share_num = 1; g_grid_coop_share_den = 2;
     if (const char* s = getenv("RT_GRID_COOP_SHARE")) { g_grid_coop_share_num = (uint32_t)strtoul(s, nullptr, 10); g_grid_coop_share_den = 100; }

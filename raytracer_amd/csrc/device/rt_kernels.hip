@@ -678,13 +678,19 @@ RT_DEV uint64_t grid_cell_from_point(V3 p, const DGrid& g) {            // grid.
 template <bool DRAW>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
-                                                          double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
+                                                          double tmin0, double tmax0, ExtendOut out, uint32_t* fetch_ctr, unsigned long long* stats) {
     const uint64_t n = count ? (uint64_t)*count : n_fixed;
-    const uint32_t nb = gridDim.x, T = nb * RT_BLOCK;
-    const uint32_t tid = xcd_chunk(blockIdx.x, nb) * RT_BLOCK + threadIdx.x;
     const double INF = __builtin_huge_val();
     uint64_t c_box = 0, c_prim = 0, c_steps = 0, c_gbox = 0, c_rays = 0;
-    for (uint64_t q = tid; q < n; q += T) {
+    // 64 consecutive rays per wave and pass, handed out through a counter (as in k_extend_grid_coop): rays differ by orders of
+    // magnitude in cost, a static split leaves wave slots idle towards the end of a launch
+    for (;;) {
+        uint32_t base32 = 0;
+        if ((threadIdx.x & 63) == 0) base32 = atomicAdd(fetch_ctr, 64u);
+        const uint64_t qbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)base32);
+        if (qbase >= n) break;
+        const uint64_t q = qbase + (threadIdx.x & 63);
+        if (q >= n) continue;
         V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
         V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
         V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
@@ -776,8 +782,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
         stat_add(stats, ST_GRIDBOX, c_gbox); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
-template __global__ void k_extend_grid<false>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
-template __global__ void k_extend_grid<true>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, unsigned long long*);
+template __global__ void k_extend_grid<false>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, uint32_t*, unsigned long long*);
+template __global__ void k_extend_grid<true>(DGrid, const DPrim*, const DTriPre*, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, uint32_t*, unsigned long long*);
 
 // ---------------------------------------------------------------------------------------------
 // extend_grid, cooperative form (all-triangle scenes whose grid has well-filled cells).  The cell walk of Grid::traverse
@@ -825,15 +831,20 @@ __global__ void k_cell_chunks(const uint64_t* __restrict__ cell_offset, const ui
 
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
                                                                RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
-                                                               double tmin0, double tmax0, ExtendOut out, unsigned long long* stats) {
+                                                               double tmin0, double tmax0, ExtendOut out, uint32_t* fetch_ctr, unsigned long long* stats) {
     __shared__ double2 s_ray[RT_BLOCK / 64][3][64];                     // origins and directions of the wave's parked rays
     const uint64_t n = count ? (uint64_t)*count : n_fixed;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (RT_BLOCK / 64);
-    const uint64_t wave0 = (uint64_t)xcd_chunk(blockIdx.x, gridDim.x) * (RT_BLOCK / 64) + (threadIdx.x >> 6);
     const double INF = __builtin_huge_val();
     uint64_t c_box = 0, c_prim = 0, c_steps = 0, c_gbox = 0, c_rays = 0;
-    for (uint64_t base = wave0 * 64u; base < n; base += n_waves * 64u) {          // wave-uniform: 64 consecutive rays per pass
+    // 64 consecutive rays per pass, handed out through a counter: a ray that crosses a well-filled cell costs thousands of times
+    // what a ray through empty cells costs, and a static split left a third of the wave slots idle (1.5 - 2.0 of 3 resident waves
+    // per SIMD on the res4 dragon, SQ_WAVE_CYCLES)
+    for (;;) {
+        uint32_t base32 = 0;
+        if (lane == 0) base32 = atomicAdd(fetch_ctr, 64u);
+        const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)base32);
+        if (base >= n) break;
         const uint64_t q = base + lane;
         const bool valid = q < n;
         V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
@@ -1021,8 +1032,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
 // normal and front_face as sphere.rs:51-52 / triangle.rs:39-41,77 compute them.
 // The throughput is a left-to-right product where the reference nests right-to-left (camera.rs:172):
 // radiance may differ from the reference's in the last ulps; hit/miss decisions are unaffected.
+#ifndef RT_SHADE_WAVES_PF
+#define RT_SHADE_WAVES_PF 4   // the prefetching variant holds a second queue entry (26 VGPRs): 128 VGPRs, two 512-thread blocks per CU
+#endif
 #define RT_SHADE_LDS_MATS 512      // materials kept in LDS (20 KB): the third dependent global load of a shade (ray -> primitive -> material) becomes an LDS read
-__global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DMat* __restrict__ mats, uint32_t n_mats,
+// MODE bit 0: the next tile's queue entry (ray, throughput, id, hit) is loaded while the current one is shaded ("two rays per
+//             thread" as far as loads in flight go: the experiment DESIGN carried since round 1);
+// MODE bit 1: all-sphere scenes read the 48-byte DSphere (3 lane accesses) instead of the 80-byte DPrim (5).
+// Both measured in round 3 (profiles/round3_shade_variants.md).
+struct ShadeIn { V3 o, d, thr; uint32_t id; int32_t pi; double tp, tn; };
+template <int MODE>
+__global__ __launch_bounds__(RT_SBLOCK, (MODE & 1) ? RT_SHADE_WAVES_PF : RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DSphere* __restrict__ spheres, const DMat* __restrict__ mats, uint32_t n_mats,
                                                     RayQ in, const uint32_t* __restrict__ count_in,
                                                     const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
@@ -1037,6 +1057,14 @@ __global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim
     const uint64_t n = (uint64_t)*count_in;
     const uint64_t T = (uint64_t)gridDim.x * RT_SBLOCK;
     uint64_t c_scatter = 0;
+    auto fetch = [&](uint64_t q, ShadeIn& r) {
+        r.o = v3(in.ox[q], in.oy[q], in.oz[q]); r.d = v3(in.dx[q], in.dy[q], in.dz[q]);
+        r.thr = v3(in.tr[q], in.tg[q], in.tb[q]); r.id = in.id[q]; r.pi = hit_prim_[q];
+        if (MODE & 1) { r.tp = hit_tp[q]; r.tn = hit_tn ? hit_tn[q] : 0.0; }      // ahead of time: not yet known whether the ray hit
+        else if (r.pi >= 0) { r.tp = hit_tp[q]; r.tn = hit_tn ? hit_tn[q] : 0.0; }
+    };
+    ShadeIn nx; nx.o = nx.d = nx.thr = v3(0, 0, 0); nx.id = 0; nx.pi = -1; nx.tp = nx.tn = 0.0;
+    if ((MODE & 1) && (uint64_t)blockIdx.x * RT_SBLOCK + threadIdx.x < n) fetch((uint64_t)blockIdx.x * RT_SBLOCK + threadIdx.x, nx);
     for (uint64_t base = (uint64_t)blockIdx.x * RT_SBLOCK; base < n; base += T) {      // uniform per block (barriers inside)
         const uint64_t q = base + threadIdx.x;
         const bool valid = q < n;
@@ -1047,31 +1075,40 @@ __global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim
         V3 d = v3(0, 0, 0), p = v3(0, 0, 0), normal = v3(0, 0, 0), radiance = v3(0, 0, 0);
         bool surface = false, front_face = false;
         DMat m; m.albedo[0] = m.albedo[1] = m.albedo[2] = 0.0; m.param = 0.0; m.type = 2u; m.pad = 0u;
+        ShadeIn cur = nx;
+        if (MODE & 1) { if (q + T < n) fetch(q + T, nx); }           // in flight while this tile is shaded
+        else if (valid) fetch(q, cur);
         if (valid) {
-            V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
-            d = v3(in.dx[q], in.dy[q], in.dz[q]);
-            thr = v3(in.tr[q], in.tg[q], in.tb[q]);
-            id = in.id[q];
-            int32_t pi = hit_prim_[q];
+            const V3 o = cur.o;
+            d = cur.d; thr = cur.thr; id = cur.id;
+            const int32_t pi = cur.pi;
             if (pi == RT_HIT_EDGE) {                                  // camera.rs:162-164,178-180: Color::red()
                 radiance = thr * v3(1.0, 0.0, 0.0);
             } else if (pi < 0) {                                      // camera.rs:182-184
                 radiance = thr * sky_color(d);
             } else {
-                DPrim P = prims[pi];
-                double tp = hit_tp[q];
+                const double tp = cur.tp;
                 p = o + (tp * d);
-                V3 outward;
-                if (P.tm >> 31) {
-                    V3 v0 = v3(P.v[0], P.v[1], P.v[2]), v1 = v3(P.v[3], P.v[4], P.v[5]), v2 = v3(P.v[6], P.v[7], P.v[8]);
-                    outward = cross(v1 - v0, v2 - v0);
+                V3 outward; uint32_t tm;
+                if ((MODE & 2) && spheres) {                          // all-sphere scene: sphere.rs:50-52 from the 48-byte record
+                    const double2* sp2 = (const double2*)(spheres + pi);
+                    const double2 c0 = sp2[0], c1 = sp2[1]; const uint4 w2 = *(const uint4*)(sp2 + 2);
+                    tm = w2.x;
+                    outward = (p - v3(c0.x, c0.y, c1.x)) / c1.y;
                 } else {
-                    V3 pn = hit_tn ? o + (hit_tn[q] * d) : p;            // rec.p as it was when the sphere was accepted
-                    outward = (pn - v3(P.v[0], P.v[1], P.v[2])) / P.v[3];
+                    DPrim P = prims[pi];
+                    tm = P.tm;
+                    if (P.tm >> 31) {
+                        V3 v0 = v3(P.v[0], P.v[1], P.v[2]), v1 = v3(P.v[3], P.v[4], P.v[5]), v2 = v3(P.v[6], P.v[7], P.v[8]);
+                        outward = cross(v1 - v0, v2 - v0);
+                    } else {
+                        V3 pn = hit_tn ? o + (cur.tn * d) : p;            // rec.p as it was when the sphere was accepted
+                        outward = (pn - v3(P.v[0], P.v[1], P.v[2])) / P.v[3];
+                    }
                 }
                 front_face = dot(d, outward) < 0.0;                   // hittable.rs:26-29
                 normal = front_face ? outward : -outward;
-                m = mats_lds ? s_mats[P.tm & 0x7fffffffu] : mats[P.tm & 0x7fffffffu];
+                m = mats_lds ? s_mats[tm & 0x7fffffffu] : mats[tm & 0x7fffffffu];
                 surface = true;
             }
         }
@@ -1126,6 +1163,8 @@ __global__ __launch_bounds__(RT_SBLOCK, RT_SHADE_WAVES) void k_shade(const DPrim
     }
     if (stats) stat_add(stats, ST_SCATTER, c_scatter);
 }
+#define RT_INST_SHADE(M) template __global__ void k_shade<M>(const DPrim*, const DSphere*, const DMat*, uint32_t, RayQ, const uint32_t*, const int32_t*, const double*, const double*, RayQ, uint32_t*, double*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, unsigned long long*);
+RT_INST_SHADE(0) RT_INST_SHADE(1) RT_INST_SHADE(2) RT_INST_SHADE(3)
 
 // resolve: `pixel_color += ray_color(...)` (camera.rs:72) for the batch's samples, in sample order.  One lane per pixel
 // walks that pixel's contiguous run of records (rad[pixel][sample][rgb]).
