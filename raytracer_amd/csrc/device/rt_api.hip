@@ -67,6 +67,7 @@ bool g_cell_tri = true;               // RT_CELL_TRI=0: the grid walk reads list
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 uint32_t g_grid_coop_share_num = 1, g_grid_coop_share_den = 2;   // ... and only if such cells hold at least this share of all list entries (RT_GRID_COOP_SHARE, percent)
 uint32_t g_grid_coop_min = 128;       // RT_GRID_COOP_MIN: cells whose list has at least this many triangles are tested by the whole wave (k_extend_grid_coop); 0 = never
+bool g_grid_codes = true;             // RT_GRID_CODES=0: the grid walk always reads a cell's box and list offsets from the tables (A/B)
 int g_shade_mode = 3;                 // RT_SHADE_MODE bit 0: prefetch the next tile's queue entry; bit 1: 48-byte spheres in shade (k_shade<MODE>).  Both on:
                                       // weekend-final shade 58.3 -> 53.4 ms (profiles/round3_shade_variants.md); RT_SHADE_MODE=0 is the round-2 kernel
 bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
@@ -138,6 +139,7 @@ struct rt_scene {
     bool have_grid = false; DGrid grid{}; rt_grid_desc grid_desc{}; uint64_t grid_list_len = 0;
     double* d_cell_aabb = nullptr; uint64_t* d_cell_offset = nullptr; uint32_t* d_prim_list = nullptr;
     DCellTri* d_cell_tri = nullptr;    // all-triangle scenes: plane record + index per list position (k_cell_tri)
+    uint32_t* d_cell_code = nullptr;   // two bits per cell: list not empty / box not the implicit one (DGrid::cell_code)
     uint32_t* d_cell_chunk = nullptr; DCellChunk* d_chunks = nullptr; uint32_t n_chunks = 0;   // cooperative cell test: chunked lists of the well-filled cells
     Workspace ws;
 };
@@ -448,6 +450,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
+    g_grid_codes = true; if (const char* s = getenv("RT_GRID_CODES")) g_grid_codes = atoi(s) != 0;
     g_shade_mode = 3; if (const char* s = getenv("RT_SHADE_MODE")) g_shade_mode = atoi(s) & 3;
     g_grid_coop_min = 128; if (const char* s = getenv("RT_GRID_COOP_MIN")) g_grid_coop_min = (uint32_t)strtoul(s, nullptr, 10);
     g_grid_coop_share_num = 1; g_grid_coop_share_den = 2;
@@ -529,7 +532,7 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->d_pairs64) (void)hipFree(sc->d_pairs64); if (sc->d_spheres) (void)hipFree(sc->d_spheres); if (sc->d_pairsn) (void)hipFree(sc->d_pairsn);
     if (sc->d_cell_aabb) (void)hipFree(sc->d_cell_aabb); if (sc->d_cell_offset) (void)hipFree(sc->d_cell_offset); if (sc->d_prim_list) (void)hipFree(sc->d_prim_list);
     if (sc->d_cell_tri) (void)hipFree(sc->d_cell_tri);
-    if (sc->d_cell_chunk) (void)hipFree(sc->d_cell_chunk); if (sc->d_chunks) (void)hipFree(sc->d_chunks);
+    if (sc->d_cell_chunk) (void)hipFree(sc->d_cell_chunk); if (sc->d_chunks) (void)hipFree(sc->d_chunks); if (sc->d_cell_code) (void)hipFree(sc->d_cell_code);
     sc->ws.release();
     delete sc;
 }
@@ -734,6 +737,27 @@ static void install_grid(rt_scene* sc, const rt_grid_desc& gd, uint64_t list_len
         if (hipStreamSynchronize(g_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sc->d_cell_tri); sc->d_cell_tri = nullptr; }
     } else (void)hipGetLastError();
     g.cell_tri = sc->d_cell_tri;
+    // cell codes (DGrid::cell_code): only for an integer cell size that tiles the world, where slot = x + nx * (y + ny * z) names loop
+    // cell (x, y, z); k_grid_codes then checks every cell's stored box against the implicit one, so the walk may trust code 0
+    if (sc->d_cell_code) { (void)hipFree(sc->d_cell_code); sc->d_cell_code = nullptr; }
+    g.cell_code = nullptr; g.nx = g.ny = g.nz = 0;
+    {
+        bool ok = g_grid_codes && gd.n_cells < (1ull << 32);
+        uint32_t nn[3] = {0, 0, 0};
+        for (int c = 0; ok && c < 3; ++c) {
+            const double sz = gd.box_size[c], cnt = gd.total_size[c] / sz;
+            ok = sz >= 1.0 && sz == floor(sz) && cnt == floor(cnt) && cnt >= 1.0 && cnt < 65536.0 && gd.origin[c] == floor(gd.origin[c]) && fabs(gd.origin[c]) < 1e9;
+            nn[c] = ok ? (uint32_t)cnt : 0u;
+        }
+        ok = ok && (uint64_t)nn[0] * nn[1] * nn[2] == gd.n_cells;
+        if (ok && hipMalloc(&sc->d_cell_code, ((gd.n_cells + 15) / 16) * sizeof(uint32_t)) == hipSuccess) {
+            g.nx = nn[0]; g.ny = nn[1]; g.nz = nn[2];
+            const uint64_t words = (gd.n_cells + 15) / 16;
+            hipLaunchKernelGGL(k_grid_codes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, g_stream, g, sc->d_cell_code);
+            if (hipStreamSynchronize(g_stream) == hipSuccess) g.cell_code = sc->d_cell_code;
+            else { (void)hipGetLastError(); (void)hipFree(sc->d_cell_code); sc->d_cell_code = nullptr; g.nx = g.ny = g.nz = 0; }
+        } else (void)hipGetLastError();
+    }
     // cooperative cell test: chunk the lists of the cells that hold at least g_grid_coop_min triangles (optional: any failure
     // leaves the per-lane walk in charge)
     if (sc->d_cell_chunk) { (void)hipFree(sc->d_cell_chunk); sc->d_cell_chunk = nullptr; }

@@ -31,6 +31,11 @@ struct DGrid {
     // cooperative cell test (k_extend_grid_coop; all-triangle scenes): cells whose list has at least coop_min entries keep it a
     // second time as 64-entry SoA chunks; cell_chunk[cell] = index of the cell's first chunk, RT_NO_CHUNK for the other cells
     const uint32_t* cell_chunk; const DCellChunk* chunks;
+    // Two bits per cell (16 cells per word), nullable: bit 0 = the cell's list is not empty, bit 1 = the cell's stored box is NOT
+    // origin + (ix, iy, iz) * size .. + size bit for bit (clone cells, grid.rs:24-27,42-45).  A fine grid is almost all code 0:
+    // such a cell needs neither its 48-byte box nor its two list offsets from HBM (8 M cells at size 1: 450 MB of tables against
+    // a 2 MB code table that stays in L2).  nx, ny, nz = cells per axis (only set with cell_code: integer size that tiles the world).
+    const uint32_t* cell_code; uint32_t nx, ny, nz;
 };
 #define RT_NO_CHUNK 0xffffffffu
 
@@ -58,6 +63,7 @@ __global__ void k_extend_naive(const DPrim* prims, const DTriPre* pre, uint32_t 
 template <bool DRAW>
 __global__ void k_extend_grid(DGrid g, const DPrim* prims, const DTriPre* pre, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, uint32_t* fetch_ctr, unsigned long long* stats);
+__global__ void k_grid_codes(DGrid g, uint32_t* codes);
 __global__ void k_cell_chunks(const uint64_t* cell_offset, const uint32_t* prim_list, const uint32_t* big_cells, const uint32_t* big_first, uint32_t n_big,
                               const DPrim* prims, const DTriPre* pre, DCellChunk* chunks, uint32_t n_chunks);
 __global__ void k_extend_grid_coop(DGrid g, const DPrim* prims, const DTriPre* pre, RayQ in, const uint32_t* count, uint64_t n_fixed,

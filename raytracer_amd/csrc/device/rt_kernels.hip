@@ -663,6 +663,76 @@ RT_DEV uint64_t grid_index(V3 p, const DGrid& g) {
     double size_y = g.total_size.y / g.box_size.y;
     return sat_usize((double)x + (double)y * size_x + (double)z * size_x * size_y);
 }
+// get_index with the three per-axis cell numbers it computes on the way; `ok` = they are inside the grid (then, and only then,
+// index == x + nx * (y + ny * z) names the loop cell (x, y, z) and the implicit box below can be used for a code-0 cell)
+RT_DEV uint64_t grid_index_xyz(V3 p, const DGrid& g, uint32_t& cx, uint32_t& cy, uint32_t& cz, bool& ok) {
+    uint64_t x = sat_usize(p.x / g.box_size.x);
+    uint64_t y = sat_usize(p.y / g.box_size.y);
+    uint64_t z = sat_usize(p.z / g.box_size.z);
+    double size_x = g.total_size.x / g.box_size.x;
+    double size_y = g.total_size.y / g.box_size.y;
+    ok = x < g.nx && y < g.ny && z < g.nz;
+    cx = (uint32_t)x; cy = (uint32_t)y; cz = (uint32_t)z;
+    return sat_usize((double)x + (double)y * size_x + (double)z * size_x * size_y);
+}
+RT_DEV uint64_t grid_cell_from_point_xyz(V3 p, const DGrid& g, uint32_t& cx, uint32_t& cy, uint32_t& cz, bool& ok) {
+    int32_t dx = (int32_t)((uint32_t)sat_i32(floor(p.x)) - (uint32_t)sat_i32(g.origin.x));
+    int32_t dy = (int32_t)((uint32_t)sat_i32(floor(p.y)) - (uint32_t)sat_i32(g.origin.y));
+    int32_t dz = (int32_t)((uint32_t)sat_i32(floor(p.z)) - (uint32_t)sat_i32(g.origin.z));
+    double x = floor((double)dx / g.box_size.x) * g.box_size.x;
+    double y = floor((double)dy / g.box_size.y) * g.box_size.y;
+    double z = floor((double)dz / g.box_size.z) * g.box_size.z;
+    return grid_index_xyz(v3(floor(x), floor(y), floor(z)), g, cx, cy, cz, ok);
+}
+// The box of cell (x, y, z) and whether its list is empty, from the code table where it allows, from the tables otherwise.
+// Implicit box: min = origin + i * size (the loop coordinate `x as f64` of grid.rs:36-39 for an integer size), max = min + size
+// (GridBox::new, grid.rs:261-264); k_grid_codes compared exactly this expression with the stored box of every cell.
+RT_DEV bool grid_cell_box(const DGrid& g, uint64_t cell, uint32_t cx, uint32_t cy, uint32_t cz, bool xyz_ok, double* mn, double* mx, bool& empty) {
+    uint32_t code = 3u;
+    if (g.cell_code) code = (g.cell_code[cell >> 4] >> (((uint32_t)cell & 15u) * 2u)) & 3u;
+    if (xyz_ok && !(code & 2u)) {
+        mn[0] = g.origin.x + (double)cx * g.box_size.x; mn[1] = g.origin.y + (double)cy * g.box_size.y; mn[2] = g.origin.z + (double)cz * g.box_size.z;
+        mx[0] = mn[0] + g.box_size.x; mx[1] = mn[1] + g.box_size.y; mx[2] = mn[2] + g.box_size.z;
+    } else {
+        const double* cb = g.cell_aabb + cell * 6;
+        mn[0] = cb[0]; mn[1] = cb[1]; mn[2] = cb[2]; mx[0] = cb[3]; mx[1] = cb[4]; mx[2] = cb[5];
+    }
+    empty = g.cell_code && !(code & 1u);
+    return xyz_ok && !(code & 2u);
+}
+// Grid::traverse's step to the neighbour cell (grid.rs:170-181) when the current cell's box is the implicit one: next_xyz - origin is
+// then exactly (x +- 1) * size on the exit axis, the quotients of get_index (grid.rs:64-73) are exactly the integers x +- 1, y, z,
+// and its f64 index expression is exact integer arithmetic — as long as the new number stays inside [0, n) (at x == n the
+// reference's index runs into the next row; that case takes the literal code).  Saves three f64 divisions per step.
+RT_DEV bool grid_step_regular(const DGrid& g, int ex_axis, int ex_dir, uint32_t& cx, uint32_t& cy, uint32_t& cz, uint64_t& cell) {
+    uint32_t& c = ex_axis == 0 ? cx : (ex_axis == 1 ? cy : cz);
+    const uint32_t lim = ex_axis == 0 ? g.nx : (ex_axis == 1 ? g.ny : g.nz);
+    const uint32_t nc = c + (uint32_t)ex_dir;                              // ex_dir is +1 or -1; c == 0 with -1 wraps to 0xffffffff >= lim
+    if (nc >= lim) return false;
+    c = nc;
+    cell = (uint64_t)cx + (uint64_t)g.nx * ((uint64_t)cy + (uint64_t)g.ny * cz);
+    return true;
+}
+// one thread per 16 cells: the code word (DGrid::cell_code)
+__global__ void k_grid_codes(DGrid g, uint32_t* __restrict__ codes) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 16u >= g.n_cells) return;
+    uint32_t word = 0;
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint64_t c = w * 16u + k;
+        if (c >= g.n_cells) break;
+        const uint32_t cx = (uint32_t)(c % g.nx), cy = (uint32_t)((c / g.nx) % g.ny), cz = (uint32_t)(c / ((uint64_t)g.nx * g.ny));
+        const double imn[3] = {g.origin.x + (double)cx * g.box_size.x, g.origin.y + (double)cy * g.box_size.y, g.origin.z + (double)cz * g.box_size.z};
+        const double imx[3] = {imn[0] + g.box_size.x, imn[1] + g.box_size.y, imn[2] + g.box_size.z};
+        const double* cb = g.cell_aabb + c * 6;
+        bool same = cz < g.nz;
+        for (int a = 0; a < 3; ++a)
+            same = same && __double_as_longlong(cb[a]) == __double_as_longlong(imn[a]) && __double_as_longlong(cb[3 + a]) == __double_as_longlong(imx[a]);
+        const uint32_t code = (g.cell_offset[c + 1] > g.cell_offset[c] ? 1u : 0u) | (same ? 0u : 2u);
+        word |= code << (k * 2u);
+    }
+    codes[w] = word;
+}
 RT_DEV uint64_t grid_cell_from_point(V3 p, const DGrid& g) {            // grid.rs:195-206 (i32 subtraction wraps)
     int32_t dx = (int32_t)((uint32_t)sat_i32(floor(p.x)) - (uint32_t)sat_i32(g.origin.x));
     int32_t dy = (int32_t)((uint32_t)sat_i32(floor(p.y)) - (uint32_t)sat_i32(g.origin.y));
@@ -698,7 +768,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
         bool hit = false, edge = false;
         ++c_rays;
         // get_box_enter
-        uint64_t cell = grid_cell_from_point(o, g);
+        uint32_t cx = 0, cy = 0, cz = 0; bool cok = false;        // the cell as (x, y, z) when get_index's per-axis numbers are in range
+        uint64_t cell = grid_cell_from_point_xyz(o, g, cx, cy, cz, cok);
         bool have = cell < g.n_cells;
         if (!have) {
             // AABB::enter_and_exit (aabb.rs:65-88) on the outer box with Interval(0.001, inf); `<=` per axis
@@ -713,7 +784,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
             }
             if (ok) {
                 V3 point = o + d * a;                                  // grid.rs:132-136
-                cell = grid_cell_from_point(point, g);
+                cell = grid_cell_from_point_xyz(point, g, cx, cy, cz, cok);
                 have = cell < g.n_cells;
             }
         }
@@ -721,8 +792,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
         for (uint32_t depth = 0; have; ++depth) {
             if (depth > g.max_depth) break;                            // grid.rs:152
             ++c_steps;
-            const double* cb = g.cell_aabb + cell * 6;
-            double mn[3] = {cb[0], cb[1], cb[2]}, mx[3] = {cb[3], cb[4], cb[5]};
+            double mn[3], mx[3]; bool empty;
+            const bool implicit_box = grid_cell_box(g, cell, cx, cy, cz, cok, mn, mx, empty);
             // AABB::hit with Interval::universe (aabb.rs:28-62) keeping the Exit
             double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
             double a = -INF, b = INF; int ex_axis = 0, ex_dir = 0; bool ok = true;
@@ -739,7 +810,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
             HitState copy = rec;
             bool any = false;
             double closest = tmax0;
-            uint64_t lo = g.cell_offset[cell], hi = g.cell_offset[cell + 1];
+            uint64_t lo = 0, hi = 0;
+            if (!empty) { lo = g.cell_offset[cell]; hi = g.cell_offset[cell + 1]; }
             if (g.cell_tri) {
                 for (uint64_t k = lo; k < hi; ++k) {
                     ++c_prim;
@@ -772,7 +844,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* 
             bool inside = g.origin.x <= next_xyz.x && g.end.x >= next_xyz.x && g.origin.y <= next_xyz.y && g.end.y >= next_xyz.y
                        && g.origin.z <= next_xyz.z && g.end.z >= next_xyz.z;   // grid.rs:186-192
             if (!inside) break;
-            cell = grid_index(next_xyz - g.origin, g);                 // grid.rs:76-83
+            if (!(implicit_box && grid_step_regular(g, ex_axis, ex_dir, cx, cy, cz, cell)))
+                cell = grid_index_xyz(next_xyz - g.origin, g, cx, cy, cz, cok);   // grid.rs:76-83
             if (cell >= g.n_cells) break;
         }
         store_hit(out, q, hit, rec, prims, edge);
@@ -853,10 +926,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
         HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
         bool hit = false;
         uint64_t cell = 0;
+        uint32_t cx = 0, cy = 0, cz = 0; bool cok = false, implicit_box = false;
         bool walking = false;
         if (valid) {
             ++c_rays;
-            cell = grid_cell_from_point(o, g);                          // get_box_enter (grid.rs:119-129)
+            cell = grid_cell_from_point_xyz(o, g, cx, cy, cz, cok);    // get_box_enter (grid.rs:119-129)
             walking = cell < g.n_cells;
             if (!walking) {
                 double mn[3] = {g.origin.x, g.origin.y, g.origin.z}, mx[3] = {g.end.x, g.end.y, g.end.z};
@@ -868,7 +942,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
                     else { if (t1 > a) a = t1; if (t0 < b) b = t0; }
                     if (b <= a) { ok = false; break; }
                 }
-                if (ok) { cell = grid_cell_from_point(o + d * a, g); walking = cell < g.n_cells; }
+                if (ok) { cell = grid_cell_from_point_xyz(o + d * a, g, cx, cy, cz, cok); walking = cell < g.n_cells; }
             }
         }
         uint32_t depth = 0;
@@ -891,7 +965,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
             const bool inside = g.origin.x <= next_xyz.x && g.end.x >= next_xyz.x && g.origin.y <= next_xyz.y && g.end.y >= next_xyz.y
                              && g.origin.z <= next_xyz.z && g.end.z >= next_xyz.z;   // grid.rs:186-192
             if (!inside) { walking = false; return; }
-            cell = grid_index(next_xyz - g.origin, g);                 // grid.rs:76-83
+            if (!(implicit_box && grid_step_regular(g, ex_axis, ex_dir, cx, cy, cz, cell)))
+                cell = grid_index_xyz(next_xyz - g.origin, g, cx, cy, cz, cok);   // grid.rs:76-83
             if (cell >= g.n_cells) walking = false;
             ++depth;
         };
@@ -902,8 +977,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
                     if (depth > g.max_depth) { walking = false; }      // grid.rs:152
                     else {
                         ++c_steps;
-                        const double* cb = g.cell_aabb + cell * 6;
-                        double mn[3] = {cb[0], cb[1], cb[2]}, mx[3] = {cb[3], cb[4], cb[5]};
+                        double mn[3], mx[3]; bool empty;
+                        implicit_box = grid_cell_box(g, cell, cx, cy, cz, cok, mn, mx, empty);
                         double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
                         double a = -INF, b = INF; bool ok = true; ex_axis = 0; ex_dir = 0;
                         for (int ax = 0; ax < 3; ++ax) {                // AABB::hit with Interval::universe keeping the Exit (aabb.rs:28-62)
@@ -916,8 +991,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
                         else {
                             ++c_gbox;
                             cell_b = b; cmn0 = mn[0]; cmn1 = mn[1]; cmn2 = mn[2];
-                            const uint64_t lo = g.cell_offset[cell], hi = g.cell_offset[cell + 1];
-                            const uint32_t ck = g.cell_chunk[cell];
+                            uint64_t lo = 0, hi = 0; uint32_t ck = RT_NO_CHUNK;
+                            if (!empty) { lo = g.cell_offset[cell]; hi = g.cell_offset[cell + 1]; ck = g.cell_chunk[cell]; }
                             any = false;
                             if (ck != RT_NO_CHUNK) {                   // long list: wait for the wave
                                 parked = true; walking = false; pk_chunk = ck; pk_len = (uint32_t)(hi - lo);

@@ -15,7 +15,7 @@ run() { # name, rocprof flags...
   local rc=$?; echo "$name rc=$rc"; return $rc
 }
 run trace --kernel-trace --stats || exit 1
-run sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY || exit 1
+run sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE || exit 1
 run tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
 run fetch --pmc FETCH_SIZE || exit 1
 run write --pmc WRITE_SIZE || exit 1

@@ -76,6 +76,8 @@ for k, c in tot.items():
         for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
             if c.get(n):
                 d.append(f"{n}/WAVE_CYCLES = {c[n]/c['SQ_WAVE_CYCLES']:.3f}")
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_WAVE_CYCLES"):
+        d.append(f"mean resident waves per SIMD = {c['SQ_WAVE_CYCLES']*4.0/(c['GRBM_GUI_ACTIVE']/8.0)/1024.0:.2f} (SQ_WAVE_CYCLES counts quad-cycles; GRBM_GUI_ACTIVE is summed over 8 XCDs)")
     if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
         d.append(f"L2 hit rate = {c['TCC_HIT_sum']/(c['TCC_HIT_sum']+c['TCC_MISS_sum']):.3f}")
     if c.get("FETCH_SIZE") is not None:
