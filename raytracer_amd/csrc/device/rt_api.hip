@@ -67,6 +67,7 @@ bool g_cell_tri = true;               // RT_CELL_TRI=0: the grid walk reads list
 bool g_compact = true;                // use the f32-lattice node/triangle forms when a scene allows it (RT_COMPACT=0 disables)
 uint32_t g_grid_coop_share_num = 1, g_grid_coop_share_den = 2;   // ... and only if such cells hold at least this share of all list entries (RT_GRID_COOP_SHARE, percent)
 uint32_t g_grid_coop_min = 128;       // RT_GRID_COOP_MIN: cells whose list has at least this many triangles are tested by the whole wave (k_extend_grid_coop); 0 = never
+bool g_cell_tri_always = false;       // RT_CELL_TRI=2: per-position plane records also for sparse grids
 bool g_grid_codes = true;             // RT_GRID_CODES=0: the grid walk always reads a cell's box and list offsets from the tables (A/B)
 int g_shade_mode = 3;                 // RT_SHADE_MODE bit 0: prefetch the next tile's queue entry; bit 1: 48-byte spheres in shade (k_shade<MODE>).  Both on:
                                       // weekend-final shade 58.3 -> 53.4 ms (profiles/round3_shade_variants.md); RT_SHADE_MODE=0 is the round-2 kernel
@@ -458,7 +459,8 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_LG_SAMPLES")) { int v = atoi(s); if (v >= 0 && v <= 7) g_lg_samples = v; }
     if (const char* s = getenv("RT_TRI_PRE")) g_tri_pre = atoi(s) != 0;
     if (const char* s = getenv("RT_BOUNCE_LOG")) g_bounce_log = atoi(s) != 0;
-    if (const char* s = getenv("RT_CELL_TRI")) g_cell_tri = atoi(s) != 0;
+    g_cell_tri_always = false;
+    if (const char* s = getenv("RT_CELL_TRI")) { g_cell_tri = atoi(s) != 0; g_cell_tri_always = atoi(s) == 2; }
     if (const char* s = getenv("RT_TUNE")) g_tune = (uint32_t)strtoul(s, nullptr, 0);
     if (const char* s = getenv("RT_STREAM_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 8 && v <= 65536) g_stream_blocks = (uint32_t)v & ~7u; }
     if (const char* s = getenv("RT_ACC_BLOCKS")) { unsigned long v = strtoul(s, nullptr, 10); if (v >= 1 && v <= 1048576) g_acc_blocks = (uint32_t)v; }
@@ -731,7 +733,7 @@ static void install_grid(rt_scene* sc, const rt_grid_desc& gd, uint64_t list_len
     if (sc->d_cell_tri) { (void)hipFree(sc->d_cell_tri); sc->d_cell_tri = nullptr; }
     // optional (the walk falls back to the per-triangle plane records): 48 B per list position, at most 8 GiB; only where cells
     // hold many triangles (res4 dragon at 900x506x50: size 25 1 679 -> 1 469 ms, size 5 349 -> 322 ms, size 2 equal, size 1 +4 %)
-    if (g_cell_tri && sc->d_tri_pre && list_len && list_len * 10ull >= gd.n_cells && list_len <= (8ull << 30) / sizeof(DCellTri)
+    if (g_cell_tri && sc->d_tri_pre && list_len && (list_len * 10ull >= gd.n_cells || g_cell_tri_always) && list_len <= (8ull << 30) / sizeof(DCellTri)
         && hipMalloc(&sc->d_cell_tri, list_len * sizeof(DCellTri)) == hipSuccess) {
         hipLaunchKernelGGL(k_cell_tri, dim3((unsigned)((list_len + 255) / 256)), dim3(256), 0, g_stream, sc->d_prim_list, sc->d_tri_pre, list_len, sc->d_cell_tri);
         if (hipStreamSynchronize(g_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sc->d_cell_tri); sc->d_cell_tri = nullptr; }

@@ -745,110 +745,144 @@ RT_DEV uint64_t grid_cell_from_point(V3 p, const DGrid& g) {            // grid.
 
 // extend_grid: HittableList::hit, grid arm (hittable_list.rs:94-100) = Grid::hit (grid.rs:139-147):
 // get_box_enter (:119-129) then the tail-recursive traverse (:151-183) as a loop.
+// The walk is written as a loop over cell steps with a refill point: when RT_GRID_REFILL lanes of the wave are idle they take the
+// next rays of the queue (one atomic per refill).  Measured on the res4 dragon, 900x506x50 (round 3): refilling early LOSES —
+// size 1: 142 ms at 64 (= a fresh batch only when every lane is done), 153 at 32, 172 at 16, 198 at 8; size 2: 145 vs 226 at 16;
+// weekend-final size 5: 55 vs 74 — rays that enter a wave mid-walk stand in unrelated cells, so the box / list loads of a step stop
+// sharing cache lines and every step pays the set-up code for a few lanes.  (Lane utilisation at 64 is 0.28; it is the price of
+// coherent loads here.)  The default is therefore 64: batches of 64 consecutive rays handed out through the counter.
+#ifndef RT_GRID_REFILL
+#define RT_GRID_REFILL 64
+#endif
 template <bool DRAW>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
                                                           RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out, uint32_t* fetch_ctr, unsigned long long* stats) {
     const uint64_t n = count ? (uint64_t)*count : n_fixed;
+    const uint32_t lane = threadIdx.x & 63;
     const double INF = __builtin_huge_val();
     uint64_t c_box = 0, c_prim = 0, c_steps = 0, c_gbox = 0, c_rays = 0;
-    // 64 consecutive rays per wave and pass, handed out through a counter (as in k_extend_grid_coop): rays differ by orders of
-    // magnitude in cost, a static split leaves wave slots idle towards the end of a launch
+    bool active = false, exhausted = false;                        // exhausted is wave-uniform
+    uint64_t q = 0;
+    V3 o = v3(0, 0, 0), d = v3(1, 1, 1), inv = v3(1, 1, 1);
+    HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+    bool hit = false, edge = false;
+    uint32_t cx = 0, cy = 0, cz = 0, depth = 0; bool cok = false;  // the cell as (x, y, z) when get_index's per-axis numbers are in range
+    uint64_t cell = 0;
     for (;;) {
-        uint32_t base32 = 0;
-        if ((threadIdx.x & 63) == 0) base32 = atomicAdd(fetch_ctr, 64u);
-        const uint64_t qbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)base32);
-        if (qbase >= n) break;
-        const uint64_t q = qbase + (threadIdx.x & 63);
-        if (q >= n) continue;
-        V3 o = v3(in.ox[q], in.oy[q], in.oz[q]);
-        V3 d = v3(in.dx[q], in.dy[q], in.dz[q]);
-        V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        HitState rec; rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
-        bool hit = false, edge = false;
-        ++c_rays;
-        // get_box_enter
-        uint32_t cx = 0, cy = 0, cz = 0; bool cok = false;        // the cell as (x, y, z) when get_index's per-axis numbers are in range
-        uint64_t cell = grid_cell_from_point_xyz(o, g, cx, cy, cz, cok);
-        bool have = cell < g.n_cells;
-        if (!have) {
-            // AABB::enter_and_exit (aabb.rs:65-88) on the outer box with Interval(0.001, inf); `<=` per axis
-            double mn[3] = {g.origin.x, g.origin.y, g.origin.z}, mx[3] = {g.end.x, g.end.y, g.end.z};
-            double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
-            double a = 0.001, b = INF; bool ok = true;
-            for (int ax = 0; ax < 3; ++ax) {
-                double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
-                if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) b = t1; }
-                else { if (t1 > a) a = t1; if (t0 < b) b = t0; }
-                if (b <= a) { ok = false; break; }
-            }
-            if (ok) {
-                V3 point = o + d * a;                                  // grid.rs:132-136
-                cell = grid_cell_from_point_xyz(point, g, cx, cy, cz, cok);
-                have = cell < g.n_cells;
+        // ---- refill
+        const unsigned long long idle = ballot64(!active);
+        const uint32_t n_idle = popc64(idle);
+        if (!exhausted && n_idle >= RT_GRID_REFILL) {
+            uint32_t base32 = 0;
+            if (lane == 0) base32 = atomicAdd(fetch_ctr, n_idle);
+            const uint64_t qbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)base32);
+            if (qbase + n_idle >= n) exhausted = true;
+            const uint64_t myq = qbase + popc64(idle & ((1ull << lane) - 1ull));
+            if (!active && myq < n) {
+                q = myq;
+                o = v3(in.ox[q], in.oy[q], in.oz[q]);
+                d = v3(in.dx[q], in.dy[q], in.dz[q]);
+                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                rec.t = 0.0; rec.tp = 0.0; rec.tn = 0.0; rec.prim = -1;
+                hit = false; edge = false; depth = 0;
+                ++c_rays;
+                // get_box_enter
+                cell = grid_cell_from_point_xyz(o, g, cx, cy, cz, cok);
+                bool have = cell < g.n_cells;
+                if (!have) {
+                    // AABB::enter_and_exit (aabb.rs:65-88) on the outer box with Interval(0.001, inf); `<=` per axis
+                    double mn[3] = {g.origin.x, g.origin.y, g.origin.z}, mx[3] = {g.end.x, g.end.y, g.end.z};
+                    double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+                    double a = 0.001, b = INF; bool ok = true;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
+                        if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) b = t1; }
+                        else { if (t1 > a) a = t1; if (t0 < b) b = t0; }
+                        if (b <= a) { ok = false; break; }
+                    }
+                    if (ok) {
+                        V3 point = o + d * a;                                  // grid.rs:132-136
+                        cell = grid_cell_from_point_xyz(point, g, cx, cy, cz, cok);
+                        have = cell < g.n_cells;
+                    }
+                }
+                if (have) active = true;
+                else store_hit(out, q, false, rec, prims, false);             // never entered the grid
             }
         }
-        // traverse
-        for (uint32_t depth = 0; have; ++depth) {
-            if (depth > g.max_depth) break;                            // grid.rs:152
-            ++c_steps;
-            double mn[3], mx[3]; bool empty;
-            const bool implicit_box = grid_cell_box(g, cell, cx, cy, cz, cok, mn, mx, empty);
-            // AABB::hit with Interval::universe (aabb.rs:28-62) keeping the Exit
-            double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
-            double a = -INF, b = INF; int ex_axis = 0, ex_dir = 0; bool ok = true;
-            for (int ax = 0; ax < 3; ++ax) {
-                double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
-                if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) { b = t1; ex_axis = ax; ex_dir = 1; } }
-                else { if (t1 > a) a = t1; if (t0 < b) { b = t0; ex_axis = ax; ex_dir = -1; } }
-                if (b < a) { ok = false; break; }
-            }
-            if (!ok) break;                                            // grid.rs:155-156
-            if (DRAW && box_is_edge(mn, mx, o + a * d)) edge = true;   // aabb.rs:57-60, on the real rec (grid.rs:155)
-            // GridBox::hit on a copy of rec (grid.rs:160-167, 281-294)
-            ++c_gbox;
-            HitState copy = rec;
-            bool any = false;
-            double closest = tmax0;
-            uint64_t lo = 0, hi = 0;
-            if (!empty) { lo = g.cell_offset[cell]; hi = g.cell_offset[cell + 1]; }
-            if (g.cell_tri) {
-                for (uint64_t k = lo; k < hi; ++k) {
-                    ++c_prim;
-                    const DCellTri ct = g.cell_tri[k];
-                    if (hit_triangle_cell(prims, ct, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+        if (ballot64(active) == 0) { if (exhausted) break; continue; }
+        // ---- one cell of the traverse (grid.rs:151-183) for every lane that holds a ray
+        if (active) {
+            bool done = false;
+            if (depth > g.max_depth) done = true;                      // grid.rs:152
+            else {
+                ++c_steps;
+                double mn[3], mx[3]; bool empty;
+                const bool implicit_box = grid_cell_box(g, cell, cx, cy, cz, cok, mn, mx, empty);
+                // AABB::hit with Interval::universe (aabb.rs:28-62) keeping the Exit
+                double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+                double a = -INF, b = INF; int ex_axis = 0, ex_dir = 0; bool ok = true;
+                for (int ax = 0; ax < 3; ++ax) {
+                    double t0 = (mn[ax] - oo[ax]) * ii[ax], t1 = (mx[ax] - oo[ax]) * ii[ax];
+                    if (t0 < t1) { if (t0 > a) a = t0; if (t1 < b) { b = t1; ex_axis = ax; ex_dir = 1; } }
+                    else { if (t1 > a) a = t1; if (t0 < b) { b = t0; ex_axis = ax; ex_dir = -1; } }
+                    if (b < a) { ok = false; break; }
                 }
-            } else if (pre) {
-                for (uint64_t k = lo; k < hi; ++k) {
-                    ++c_prim;
-                    uint32_t pi = g.prim_list[k];
-                    if (hit_triangle_pre(prims, pre, pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
-                }
-            } else {
-                for (uint64_t k = lo; k < hi; ++k) {
-                    ++c_prim;
-                    uint32_t pi = g.prim_list[k];
-                    DPrim P = prims[pi];
-                    if (hit_prim(P, (int32_t)pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                if (!ok) done = true;                                  // grid.rs:155-156
+                else {
+                    if (DRAW && box_is_edge(mn, mx, o + a * d)) edge = true;   // aabb.rs:57-60, on the real rec (grid.rs:155)
+                    // GridBox::hit on a copy of rec (grid.rs:160-167, 281-294)
+                    ++c_gbox;
+                    HitState copy = rec;
+                    bool any = false;
+                    double closest = tmax0;
+                    uint64_t lo = 0, hi = 0;
+                    if (!empty) { lo = g.cell_offset[cell]; hi = g.cell_offset[cell + 1]; }
+                    if (g.cell_tri) {
+                        for (uint64_t k = lo; k < hi; ++k) {
+                            ++c_prim;
+                            const DCellTri ct = g.cell_tri[k];
+                            if (hit_triangle_cell(prims, ct, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                        }
+                    } else if (pre) {
+                        for (uint64_t k = lo; k < hi; ++k) {
+                            ++c_prim;
+                            uint32_t pi = g.prim_list[k];
+                            if (hit_triangle_pre(prims, pre, pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                        }
+                    } else {
+                        for (uint64_t k = lo; k < hi; ++k) {
+                            ++c_prim;
+                            uint32_t pi = g.prim_list[k];
+                            DPrim P = prims[pi];
+                            if (hit_prim(P, (int32_t)pi, o, d, tmin0, closest, copy)) { any = true; closest = copy.t; }
+                        }
+                    }
+                    if (any) {
+                        rec = copy;
+                        if (rec.t <= b) { hit = true; done = true; }
+                    }
+                    if (!done) {
+                        ++c_box;                                               // grid.rs:172
+                        V3 step = v3(0, 0, 0);                                 // aabb.rs:161-165
+                        double sv = (double)ex_dir * (ex_axis == 0 ? g.box_size.x : (ex_axis == 1 ? g.box_size.y : g.box_size.z));
+                        if (ex_axis == 0) step.x = sv; else if (ex_axis == 1) step.y = sv; else step.z = sv;
+                        V3 next_xyz = v3(mn[0], mn[1], mn[2]) + step;
+                        bool inside = g.origin.x <= next_xyz.x && g.end.x >= next_xyz.x && g.origin.y <= next_xyz.y && g.end.y >= next_xyz.y
+                                   && g.origin.z <= next_xyz.z && g.end.z >= next_xyz.z;   // grid.rs:186-192
+                        if (!inside) done = true;
+                        else {
+                            if (!(implicit_box && grid_step_regular(g, ex_axis, ex_dir, cx, cy, cz, cell)))
+                                cell = grid_index_xyz(next_xyz - g.origin, g, cx, cy, cz, cok);   // grid.rs:76-83
+                            if (cell >= g.n_cells) done = true;
+                            ++depth;
+                        }
+                    }
                 }
             }
-            if (any) {
-                rec = copy;
-                if (rec.t <= b) { hit = true; break; }
-            }
-            ++c_box;                                                   // grid.rs:172
-            V3 step = v3(0, 0, 0);                                     // aabb.rs:161-165
-            double sv = (double)ex_dir * (ex_axis == 0 ? g.box_size.x : (ex_axis == 1 ? g.box_size.y : g.box_size.z));
-            if (ex_axis == 0) step.x = sv; else if (ex_axis == 1) step.y = sv; else step.z = sv;
-            V3 next_xyz = v3(mn[0], mn[1], mn[2]) + step;
-            bool inside = g.origin.x <= next_xyz.x && g.end.x >= next_xyz.x && g.origin.y <= next_xyz.y && g.end.y >= next_xyz.y
-                       && g.origin.z <= next_xyz.z && g.end.z >= next_xyz.z;   // grid.rs:186-192
-            if (!inside) break;
-            if (!(implicit_box && grid_step_regular(g, ex_axis, ex_dir, cx, cy, cz, cell)))
-                cell = grid_index_xyz(next_xyz - g.origin, g, cx, cy, cz, cok);   // grid.rs:76-83
-            if (cell >= g.n_cells) break;
+            if (done) { store_hit(out, q, hit, rec, prims, edge); active = false; }
         }
-        store_hit(out, q, hit, rec, prims, edge);
     }
     if (stats) {
         stat_add(stats, ST_BOX, c_box); stat_add(stats, ST_PRIM, c_prim); stat_add(stats, ST_STEPS, c_steps);
