@@ -226,7 +226,8 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
         if (sc->draw_boxes)
             hipLaunchKernelGGL(k_extend_grid<true>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
         else if (sc->n_chunks && sc->d_tri_pre)          // some cells are well filled: the whole wave tests their lists (all-triangle scenes)
-            hipLaunchKernelGGL(k_extend_grid_coop, grid, block, 0, st, sc->grid, sc->d_prims, sc->d_tri_pre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
+            // always the full grid: a short queue is spread thinly over all waves (see the kernel), not packed into a few
+            hipLaunchKernelGGL(k_extend_grid_coop, dim3(g_extend_blocks), block, 0, st, sc->grid, sc->d_prims, sc->d_tri_pre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
         else
             hipLaunchKernelGGL(k_extend_grid<false>, grid, block, 0, st, sc->grid, sc->d_prims, gpre, in, count, n_fixed, tmin, tmax, out, fetch_ctr, d_stats);
         break;

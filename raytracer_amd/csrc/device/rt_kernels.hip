@@ -908,6 +908,9 @@ template __global__ void k_extend_grid<true>(DGrid, const DPrim*, const DTriPre*
 //   * rec.t is the t of the LAST entry that passed the plane test, rec.p's parameter that of the last one that also had t >= 0
 //     (triangle.rs:52,59 write before acceptance), the primitive / normal those of the last accepted entry.
 // Every counter is what the per-lane walk counts (one primitive test per list entry).
+#ifndef RT_COOP_WAVES
+#define RT_COOP_WAVES 4       // waves per SIMD the cooperative kernel is compiled for: 128 VGPRs with 43 spilled beat 161 VGPRs at 3 waves (res4 grid 25: 536 -> 503 ms, grid 5 equal)
+#endif
 RT_DEV double rl_f64(double x, uint32_t k) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), (int)k), __builtin_amdgcn_readlane(__double2loint(x), (int)k));
 }
@@ -936,7 +939,7 @@ __global__ void k_cell_chunks(const uint64_t* __restrict__ cell_offset, const ui
     ch.pad[l] = 0u;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
+__global__ __launch_bounds__(RT_BLOCK, RT_COOP_WAVES) void k_extend_grid_coop(DGrid g, const DPrim* __restrict__ prims, const DTriPre* __restrict__ pre,
                                                                RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                                double tmin0, double tmax0, ExtendOut out, uint32_t* fetch_ctr, unsigned long long* stats) {
     __shared__ double2 s_ray[RT_BLOCK / 64][3][64];                     // origins and directions of the wave's parked rays
@@ -947,13 +950,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_grid_coop(DGrid g, const DP
     // 64 consecutive rays per pass, handed out through a counter: a ray that crosses a well-filled cell costs thousands of times
     // what a ray through empty cells costs, and a static split left a third of the wave slots idle (1.5 - 2.0 of 3 resident waves
     // per SIMD on the res4 dragon, SQ_WAVE_CYCLES)
+    // A short queue (the last ~45 bounces of a frame carry a few thousand rays each) is spread over the waves of the grid in
+    // batches of fewer than 64 rays: a wave serves its parked rays one after the other, so 64 rays in one wave are a chain of
+    // hundreds of dependent chunk loads while most of the chip idles (res4 size 5: 0.8-2 ms per such launch).
+    const uint64_t n_waves_grid = (uint64_t)gridDim.x * (RT_BLOCK / 64);
+    uint32_t bsz = 64u;
+    if (n < 64u * n_waves_grid) { const uint64_t per = (n + n_waves_grid - 1) / n_waves_grid; bsz = per < 1 ? 1u : (uint32_t)per; }
     for (;;) {
         uint32_t base32 = 0;
-        if (lane == 0) base32 = atomicAdd(fetch_ctr, 64u);
+        if (lane == 0) base32 = atomicAdd(fetch_ctr, bsz);
         const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)base32);
         if (base >= n) break;
         const uint64_t q = base + lane;
-        const bool valid = q < n;
+        const bool valid = lane < bsz && q < n;
         V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
         if (valid) { o = v3(in.ox[q], in.oy[q], in.oz[q]); d = v3(in.dx[q], in.dy[q], in.dz[q]); }
         const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
