@@ -102,7 +102,7 @@ int rth_run(int argc, const char* const* argv) {
     if (!parse_cli(argc, argv, cli, g_err)) return 2;
     // --gpus N forks its workers, and a forked copy of a process that has initialised HIP (any embedding host is likely to
     // have) cannot use the GPU: the flag belongs to the `raytracer` binary, which forks before its first HIP call
-    if (cli.gpus > 1) { g_err = "--gpus needs the raytracer binary (the workers are forked before any HIP call); in-process hosts split samples with rt_render_device"; return 2; }
+    if (cli.gpus > 1 || cli.reduce == 1) { g_err = "--gpus / --reduce rccl need the raytracer binary (the workers are forked before any HIP call); in-process hosts split samples with rt_render_device"; return 2; }
     return run(cli, nullptr, g_err);
 }
 // pieces of the CLI surface, exposed for tests

@@ -186,7 +186,7 @@ def test_cli_binary_help_and_errors():
     if not os.path.exists(exe):
         pytest.skip("CLI not built")
     r = subprocess.run([exe, "--help"], capture_output=True, text=True)
-    assert r.returncode == 0 and "--algorithm" in r.stdout and "--grid-size" in r.stdout
+    assert r.returncode == 0 and "--algorithm" in r.stdout and "--grid-size" in r.stdout and "--reduce" in r.stdout
     r = subprocess.run([exe, "scenes/simple_fuzzy_metal.json", "-o", "bvh-naive", "-o", "bvh-sah-plane"], capture_output=True, text=True)
     assert r.returncode != 0 and "Can't have the following options at the same time" in r.stderr
     r = subprocess.run([exe, "scenes/simple_fuzzy_metal.json", "--stats"], capture_output=True, text=True)
@@ -296,3 +296,7 @@ def test_in_process_run_refuses_gpus_flag():
     from raytracer_amd.host import RtError
     with pytest.raises(RtError, match="raytracer binary"):
         rt.run(["scenes/simple_fuzzy_metal.json", "--gpus", "2"])
+    with pytest.raises(RtError, match="raytracer binary"):              # one worker, but a forked one
+        rt.run(["scenes/simple_fuzzy_metal.json", "--gpus", "1", "--reduce", "rccl"])
+    with pytest.raises(RtError, match="possible values: auto, rccl, host"):
+        rt.run(["scenes/simple_fuzzy_metal.json", "--reduce", "nccl"])
