@@ -525,6 +525,8 @@ void rt_scene_destroy(rt_scene* sc) {
             fprintf(stderr, "[stamps] internal phases on one pair (wave-uniform): %.4f of the phases, %.4f of the lane visits; >= 3/4 of the lanes on the first lane's pair: %.4f of the phases\n",
                     h[6] ? (double)h[13] / h[6] : 0.0, h[8] ? (double)h[14] / h[8] : 0.0, h[6] ? (double)h[15] / h[6] : 0.0);
             fprintf(stderr, "[stamps] continuations that entered an internal node (DPairN box re-fetches): %llu = %.4f per internal visit\n", h[16], h[17] ? (double)h[16] / h[17] : 0.0);
+            fprintf(stderr, "[stamps] continuation stack: %.3f pushes per ray, %.4f of them leave the %d-entry LDS window for HBM (%.4f per ray)\n",
+                    h[20] ? (double)h[19] / h[20] : 0.0, h[19] ? (double)h[18] / h[19] : 0.0, RT_STK, h[20] ? (double)h[18] / h[20] : 0.0);
             (void)hipMemset(g_dbg, 0, sizeof h);
         }
     }

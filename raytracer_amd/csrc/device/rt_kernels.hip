@@ -260,9 +260,10 @@ template __global__ void k_extend_bvh<true>(const DNode*, const DPrim*, RayQ, co
 // dbg: 0 loop cycles, 1 refill cycles, 2 internal cycles, 3 leaf cycles, 4 iterations, 5 refill iterations, 6 internal
 // iterations, 7 leaf iterations, 8 lanes served by internal phases, 9 lanes served by leaf phases, 10 lanes refilled,
 // 11 live lanes summed over iterations, 12 waves, 13 internal phases whose lanes all stand on ONE pair (what a scalar-load
-// path could serve), 14 lanes in those, 15 internal phases where at least 3/4 of the lanes stand on the first lane's pair
+// path could serve), 14 lanes in those, 15 internal phases where at least 3/4 of the lanes stand on the first lane's pair;
+// per-lane sums: 16 own-box re-reads (DPairN), 17 internal visits, 18 stack entries moved from the LDS window to HBM, 19 pushes, 20 rays
 #ifdef RT_STAMPS
-#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0, n_uni = 0, l_uni = 0, n_uni2 = 0, n_refetch = 0; const unsigned long long tk_begin = clock64();
+#define RT_STAMP_DECL unsigned long long tk0 = 0, tk_ref = 0, tk_int = 0, tk_leaf = 0, n_it = 0, n_ref = 0, n_intp = 0, n_leafp = 0, l_int = 0, l_leaf = 0, l_ref = 0, l_live = 0, n_uni = 0, l_uni = 0, n_uni2 = 0, n_refetch = 0, n_spill = 0, n_push = 0; const unsigned long long tk_begin = clock64();
 #define RT_STAMP(...) __VA_ARGS__
 #else
 #define RT_STAMP_DECL
@@ -482,11 +483,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 if (both) {
                     if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
                         *(uint4*)&my_spill[(uint64_t)lo * T] = s_stk[lo & (RT_STK - 1)][tx]; ++lo;     // same layout as StackEntry
+                        RT_STAMP(++n_spill;)
                     }
                     const double far_d = ld >= rd ? ld : rd;    // bvh.rs:212 f64::max of two non-NaN values
                     s_stk[sp & (RT_STK - 1)][tx] = make_uint4((uint32_t)__double2loint(far_d), (uint32_t)__double2hiint(far_d), go_right ? La : Ra,
                                                               (go_right ? Lb : Rb) | (flag ? 0x40000000u : 0u));
                     ++sp; flag = false;
+                    RT_STAMP(++n_push;)
                 }
                 cur_a = go_right ? Ra : La;
                 cur_b = (lh || rh) ? (go_right ? Rb : Lb) : RT_POP;
@@ -578,7 +581,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     }
     if (dbg) {   // per-lane counts (every lane adds its own)
         const unsigned long long rf = wave_sum(n_refetch), ci = wave_sum(c_int);
-        if (lane == 0) { atomicAdd(&dbg[16], rf); atomicAdd(&dbg[17], ci); }
+        const unsigned long long ns = wave_sum(n_spill), np = wave_sum(n_push), nr = wave_sum((unsigned long long)c_rays);
+        if (lane == 0) { atomicAdd(&dbg[16], rf); atomicAdd(&dbg[17], ci); atomicAdd(&dbg[18], ns); atomicAdd(&dbg[19], np); atomicAdd(&dbg[20], nr); }
     }
 #endif
     if (stats) {
