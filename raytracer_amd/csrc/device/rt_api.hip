@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>       // types and enums only: the functions are looked up with dlsym (rt_comm_*)
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -71,6 +72,9 @@ bool g_cell_tri_always = false;       // RT_CELL_TRI=2: per-position plane recor
 bool g_grid_codes = true;             // RT_GRID_CODES=0: the grid walk always reads a cell's box and list offsets from the tables (A/B)
 int g_shade_mode = 3;                 // RT_SHADE_MODE bit 0: prefetch the next tile's queue entry; bit 1: 48-byte spheres in shade (k_shade<MODE>).  Both on:
                                       // weekend-final shade 58.3 -> 53.4 ms (profiles/round3_shade_variants.md); RT_SHADE_MODE=0 is the round-2 kernel
+int g_lds_tree = 1;                   // RT_LDS_TREE=0: never stage a small scene's pair / primitive tables in LDS (k_extend_bvh2<..., LDS>), 2: also for short queues, 3: fail if the scene does not qualify (tests)
+uint32_t g_lds_min_rays = 1u << 16;   // RT_LDS_MIN: queues shorter than this keep the 128-thread kernel (a short queue wants its rays spread over the CUs)
+uint32_t g_lds_bytes = 0, g_cus = 256;   // per-block LDS limit and CU count of the current device
 bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
                                       // measured 8.5 % slower on the headline workload (profiles/round3_extend_variants.md), kept for the A/B
 
@@ -134,6 +138,7 @@ struct rt_scene {
     uint32_t stack_blocks = 0;         // extend blocks d_stack was sized for (RT_EXTEND_BLOCKS may change between rt_init calls)
     DPair32* d_pairs32 = nullptr; DPrim32* d_prims32 = nullptr; double lattice_scale = 0.0;   // compact forms; scale 0 = not available
     DPair64* d_pairs64 = nullptr; DSphere* d_spheres = nullptr;                               // generic pairs; spheres only for all-sphere scenes
+    uint32_t n_pairs64 = 0, n_bvh_prims = 0;                                                  // entries of d_pairs64 / d_prims_bvh (the LDS variant stages both)
     DPairN* d_pairsn = nullptr; uint32_t root_own[6] = {0, 0, 0, 0, 0, 0};                    // new-planes-only pairs (two accesses per visit), when the tree allows
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
     // grid
@@ -207,6 +212,21 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
             v.pairsn = sc->d_pairsn; for (int f = 0; f < 6; ++f) v.root_own[f] = sc->root_own[f];
             const bool c32 = g_compact && sc->lattice_scale > 0.0, sph = g_compact && sc->d_spheres != nullptr;
             const bool cn = c32 && g_pairn && sc->d_pairsn != nullptr;
+            // small scenes with generic pairs (the JSON scenes): tree and primitives fit in LDS beside a 4-entry stack window
+            v.lds_pairs16 = sc->n_pairs64 * (uint32_t)(sizeof(DPair64) / 16); v.lds_prims16 = sc->n_bvh_prims * (uint32_t)((sph ? sizeof(DSphere) : sizeof(DPrim)) / 16);
+            const size_t lds_need = ((size_t)RT_LSTK * RT_LBLOCK + v.lds_pairs16 + v.lds_prims16) * 16;
+            const uint32_t lblocks = (uint32_t)std::min<uint64_t>(g_cus, (uint64_t)sc->stack_blocks * RT_BLOCK / RT_LBLOCK);
+            const uint64_t n_known = count ? n_hint : n_fixed;        // 0 = unknown (a device-side count without a hint)
+            if (!c32 && g_lds_tree && sc->n_pairs64 && lds_need <= g_lds_bytes && lblocks > 0 && (g_lds_tree >= 2 || n_known == 0 || n_known >= g_lds_min_rays)) {
+#define RT_LAUNCH_BVH2L(P, T) do { static bool attr_set[RT_MAX_DEVICES]; \
+                if (!attr_set[g_device]) { HIPCHECK(hipFuncSetAttribute((const void*)k_extend_bvh2<0, P, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_lds_bytes)); attr_set[g_device] = true; } \
+                hipLaunchKernelGGL((k_extend_bvh2<0, P, T, true>), dim3(lblocks), dim3(RT_LBLOCK), lds_need, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, d_stats, g_dbg); } while (0)
+                if (sph) { if (out.trace) RT_LAUNCH_BVH2L(2, true); else RT_LAUNCH_BVH2L(2, false); }
+                else     { if (out.trace) RT_LAUNCH_BVH2L(0, true); else RT_LAUNCH_BVH2L(0, false); }
+#undef RT_LAUNCH_BVH2L
+                break;
+            }
+            if (g_lds_tree == 3) return fail(RT_E_STATE, "RT_LDS_TREE=3 (tests): this scene cannot take the LDS-resident kernel (lattice scene, or %zu bytes of LDS needed of %u)", lds_need, g_lds_bytes);
 #define RT_LAUNCH_BVH2(N, P, T) hipLaunchKernelGGL((k_extend_bvh2<N, P, T>), grid, block, 0, st, v, in, count, n_fixed, tmin, tmax, out, sc->d_stack, fetch_ctr, g_tune, d_stats, g_dbg)
             if (cn)       { if (out.trace) RT_LAUNCH_BVH2(2, 1, true); else RT_LAUNCH_BVH2(2, 1, false); }
             else if (c32) { if (out.trace) RT_LAUNCH_BVH2(1, 1, true); else RT_LAUNCH_BVH2(1, 1, false); }
@@ -452,6 +472,10 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
+    g_lds_tree = 1; if (const char* s = getenv("RT_LDS_TREE")) g_lds_tree = atoi(s);
+    g_lds_min_rays = 1u << 16; if (const char* s = getenv("RT_LDS_MIN")) g_lds_min_rays = (uint32_t)strtoul(s, nullptr, 10);
+    { int v = 0; HIPCHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device)); g_lds_bytes = v > 0 ? (uint32_t)v : 0;
+      HIPCHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device)); g_cus = v > 0 ? (uint32_t)v : 256; }
     g_grid_codes = true; if (const char* s = getenv("RT_GRID_CODES")) g_grid_codes = atoi(s) != 0;
     g_shade_mode = 3; if (const char* s = getenv("RT_SHADE_MODE")) g_shade_mode = atoi(s) & 3;
     g_grid_coop_min = 128; if (const char* s = getenv("RT_GRID_COOP_MIN")) g_grid_coop_min = (uint32_t)strtoul(s, nullptr, 10);
@@ -635,6 +659,7 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
             }
         HIPCHECK(hipMalloc(&sc->d_pairs64, pairs.size() * sizeof(DPair64)));
         HIPCHECK(hipMemcpy(sc->d_pairs64, pairs.data(), pairs.size() * sizeof(DPair64), hipMemcpyHostToDevice));
+        sc->n_pairs64 = (uint32_t)pairs.size(); sc->n_bvh_prims = n;
         bool all_spheres = n > 0;
         for (uint32_t k = 0; all_spheres && k < n; ++k) all_spheres = sc->h_prims[prim_index[k]].type == RT_SPHERE;
         if (all_spheres) {

@@ -3,6 +3,8 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 128          // extend kernels: two wave64 per workgroup
+#define RT_LBLOCK 1024        // extend_bvh2 with the tree in LDS: one 16-wave workgroup per CU shares one copy
+#define RT_LSTK 4             // ... and keeps four continuation-stack entries per lane in LDS instead of eight (64 KB of the 160)
 #ifndef RT_SBLOCK
 #define RT_SBLOCK 512
 #endif                        // streaming kernels (generate, shade, accumulate): block-level queue compaction
@@ -52,8 +54,9 @@ __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, co
 // tree and primitives as the persistent extend kernel reads them (rt_device.h):
 //   NODES 0 = DPair64 (f64 planes), 1 = DPair32 (lattice), 2 = DPairN (lattice, new planes only: two accesses per visit);  PRIMS 0 = DPrim (any mix), 1 = DPrim32 (lattice triangles), 2 = DSphere
 struct BvhView { const DNode* nodes; const DPrim* prims; const DPair64* pairs64; const DSphere* spheres;
-                 const DPair32* pairs32; const DPrim32* prims32; double scale; const DPairN* pairsn; uint32_t root_own[6]; };
-template <int NODES, int PRIMS, bool TRACE>
+                 const DPair32* pairs32; const DPrim32* prims32; double scale; const DPairN* pairsn; uint32_t root_own[6];
+                 uint32_t lds_pairs16, lds_prims16; };    // LDS variant: 16-byte words of pairs64 and of spheres / prims to stage
+template <int NODES, int PRIMS, bool TRACE, bool LDS = false>
 __global__ void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);
 __global__ void k_tri_pre(const DPrim* prims, uint32_t n, DTriPre* pre);

@@ -281,8 +281,11 @@ RT_DEV double lattice_minus(uint32_t f32_bits, double scale, double o) { return 
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
 #endif
-template <int NODES, int PRIMS, bool TRACE>
-__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
+// LDS = true (small scenes with generic pairs, NODES == 0): the whole pair table and primitive table are staged in LDS by a
+// 1024-thread workgroup (one per CU), so a visit's seven 16-byte reads go to LDS (128 B/clk/CU) instead of the vector L1
+// (about one divergent lane access per clock); the continuation stack keeps RT_LSTK entries per lane there.
+template <int NODES, int PRIMS, bool TRACE, bool LDS>
+__global__ __launch_bounds__(LDS ? RT_LBLOCK : RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* __restrict__ count, uint64_t n_fixed,
                                                           double tmin0, double tmax0, ExtendOut out,
                                                           StackEntry* __restrict__ spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats,
                                                           unsigned long long* dbg) {
@@ -290,13 +293,30 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
     constexpr int SH_MODE = (TRACE ? 1 : 0) | (PRIMS != 0 ? 4 : 0);      // single-type scenes never read rec.tn
     const uint32_t cost_leaf = tune & 0xffu, cost_int = (tune >> 8) & 0xffu;
     const uint32_t refill_min = ((tune >> 16) & 0xffu) > 64u ? 64u : ((tune >> 16) & 0xffu);   // a fully idle wave always refills
-    __shared__ uint4 s_stk[RT_STK][RT_BLOCK];       // {far_d lo, far_d hi, a, b | flag}: one 16-byte access per push / pop
+    static_assert(!LDS || NODES == 0, "the LDS variant stages generic pairs");
+    constexpr uint32_t BLOCK = LDS ? RT_LBLOCK : RT_BLOCK, STK = LDS ? RT_LSTK : RT_STK;
+    __shared__ uint4 s_stk_fixed[LDS ? 1 : RT_STK][LDS ? 1 : RT_BLOCK];       // {far_d lo, far_d hi, a, b | flag}: one 16-byte access per push / pop
+    extern __shared__ uint4 s_dyn[];                // LDS variant: [RT_LSTK][RT_LBLOCK] stack words, then the pairs, then the primitives
+    auto stk = [&](uint32_t level) -> uint4& {
+        if constexpr (LDS) return s_dyn[(level & (STK - 1)) * BLOCK + threadIdx.x]; else return s_stk_fixed[level & (STK - 1)][threadIdx.x];
+    };
     const uint32_t n = count ? *count : (uint32_t)n_fixed;
     // one lane per ray is all a short queue can use: surplus blocks leave before they touch the fetch counter (each wave's
     // atomic on that one word costs more than the traversal of a few hundred rays); block 0 always stays
-    if (blockIdx.x != 0 && (uint64_t)blockIdx.x * RT_BLOCK >= n) return;
-    const uint32_t T = gridDim.x * RT_BLOCK, tx = threadIdx.x, lane = tx & 63;
-    StackEntry* my_spill = spill + (blockIdx.x * RT_BLOCK + tx);
+    if (blockIdx.x != 0 && (uint64_t)blockIdx.x * BLOCK >= n) return;
+    const uint32_t T = gridDim.x * BLOCK, tx = threadIdx.x, lane = tx & 63;
+    StackEntry* my_spill = spill + (blockIdx.x * BLOCK + tx);
+    const uint4* const s_pairs = s_dyn + STK * BLOCK;
+    const uint4* const s_prims = s_pairs + bvh.lds_pairs16;
+    if constexpr (LDS) {
+        uint4* dst = s_dyn + STK * BLOCK;
+        const uint4* src = (const uint4*)bvh.pairs64;
+        for (uint32_t i = tx; i < bvh.lds_pairs16; i += BLOCK) dst[i] = src[i];
+        dst += bvh.lds_pairs16;
+        src = PRIMS == 2 ? (const uint4*)bvh.spheres : (const uint4*)bvh.prims;
+        for (uint32_t i = tx; i < bvh.lds_prims16; i += BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
     uint32_t chunk = n / ((T >> 6) * 4u);
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
     uint32_t c_next = 0, c_end = 0;          // wave-uniform: the wave's current chunk of the queue
@@ -465,7 +485,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                       asm volatile("" :: "v"(j0), "v"(j1), "v"(j2)); }
 #endif
                 } else {                                 // 112-byte pair: seven accesses
-                    const double2* pp = (const double2*)(bvh.pairs64 + cur_a);
+                    const double2* pp;
+                    if constexpr (LDS) pp = (const double2*)(s_pairs + cur_a * 7u); else pp = (const double2*)(bvh.pairs64 + cur_a);
                     const double2 b0 = pp[0], b1 = pp[1], b2 = pp[2], b3 = pp[3], b4 = pp[4], b5 = pp[5];
                     const uint4 m = *(const uint4*)(pp + 6);
                     dLmn[0] = b0.x - o.x; dLmn[1] = b0.y - o.y; dLmn[2] = b1.x - o.z;
@@ -481,12 +502,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 const bool both = lh && rh;
                 const bool go_right = rh && (!lh || ld >= rd); // bvh.rs:210-211 (tie -> right is `close`), :226-227; as lane-mask logic
                 if (both) {
-                    if (sp - lo == RT_STK) {             // LDS window full: its oldest entry goes to HBM
-                        *(uint4*)&my_spill[(uint64_t)lo * T] = s_stk[lo & (RT_STK - 1)][tx]; ++lo;     // same layout as StackEntry
+                    if (sp - lo == STK) {                // LDS window full: its oldest entry goes to HBM
+                        *(uint4*)&my_spill[(uint64_t)lo * T] = stk(lo); ++lo;     // same layout as StackEntry
                         RT_STAMP(++n_spill;)
                     }
                     const double far_d = ld >= rd ? ld : rd;    // bvh.rs:212 f64::max of two non-NaN values
-                    s_stk[sp & (RT_STK - 1)][tx] = make_uint4((uint32_t)__double2loint(far_d), (uint32_t)__double2hiint(far_d), go_right ? La : Ra,
+                    stk(sp) = make_uint4((uint32_t)__double2loint(far_d), (uint32_t)__double2hiint(far_d), go_right ? La : Ra,
                                                               (go_right ? Lb : Rb) | (flag ? 0x40000000u : 0u));
                     ++sp; flag = false;
                     RT_STAMP(++n_push;)
@@ -521,12 +542,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                     P.v[6] = lattice(q1.z, scale); P.v[7] = lattice(q1.w, scale); P.v[8] = lattice(q2.x, scale);
                     acc = hit_triangle_flat(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
                 } else if (PRIMS == 2) {             // 48-byte sphere: three accesses (the third only for parity of layout)
-                    const double2* sp2 = (const double2*)(bvh.spheres + cur_a);
+                    const double2* sp2;
+                    if constexpr (LDS) sp2 = (const double2*)(s_prims + cur_a * 3u); else sp2 = (const double2*)(bvh.spheres + cur_a);
                     const double2 c0 = sp2[0], c1 = sp2[1];
                     DPrim P; P.v[0] = c0.x; P.v[1] = c0.y; P.v[2] = c1.x; P.v[3] = c1.y;
                     acc = hit_sphere(P, (int32_t)cur_a, o, d, tmin0, tmax, rec);
                 } else {                             // 80-byte primitive: five accesses
-                    const double2* gp = (const double2*)(prims + cur_a);
+                    const double2* gp;
+                    if constexpr (LDS) gp = (const double2*)(s_prims + cur_a * 5u); else gp = (const double2*)(prims + cur_a);
                     const double2 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3];
                     const uint4 g4 = *(const uint4*)(gp + 4);
                     DPrim P; P.v[0] = g0.x; P.v[1] = g0.y; P.v[2] = g1.x; P.v[3] = g1.y; P.v[4] = g2.x; P.v[5] = g2.y; P.v[6] = g3.x; P.v[7] = g3.y;
@@ -549,8 +572,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
             // After a hit most pending far children lie behind it and are dropped one after the other; each drop used to be a
             // loop iteration of the whole wave with an LDS round trip.  The top RT_POPW entries are read at once instead.
             if (cur_b == RT_POP) {
-                uint4 w0 = s_stk[(sp - 1u) & (RT_STK - 1)][tx], w1 = s_stk[(sp - 2u) & (RT_STK - 1)][tx];
-                uint4 w2 = s_stk[(sp - 3u) & (RT_STK - 1)][tx], w3 = s_stk[(sp - 4u) & (RT_STK - 1)][tx];
+                uint4 w0 = stk(sp - 1u), w1 = stk(sp - 2u);
+                uint4 w2 = stk(sp - 3u), w3 = stk(sp - 4u);
                 asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w));
                 asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w));
                 if (sp > lo) { --sp; resume(w0); }                        // entries [lo, sp) are the ones in LDS
@@ -562,7 +585,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
                 if (sp == 0) { done = true; cur_b = RT_IDLE; }
                 else {
                     --sp;
-                    uint4 se = s_stk[sp & (RT_STK - 1)][tx];
+                    uint4 se = stk(sp);
                     asm volatile("" : "+v"(se.x), "+v"(se.y), "+v"(se.z), "+v"(se.w));      // keep this an LDS read (not a flat load of a selected pointer)
                     if (sp < lo) { lo = sp; se = *(const uint4*)&my_spill[(uint64_t)sp * T]; }
                     resume(se);
@@ -590,8 +613,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void k_extend_bvh2(BvhVi
         stat_add(stats, ST_OVERLAP, c_overlap); stat_add(stats, ST_SEGMENTS, c_rays);
     }
 }
-#define RT_INST_BVH2(N, P, T) template __global__ void k_extend_bvh2<N, P, T>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
+#define RT_INST_BVH2(N, P, T) template __global__ void k_extend_bvh2<N, P, T, false>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
 RT_INST_BVH2(0, 0, false) RT_INST_BVH2(0, 0, true) RT_INST_BVH2(0, 2, false) RT_INST_BVH2(0, 2, true) RT_INST_BVH2(1, 1, false) RT_INST_BVH2(1, 1, true) RT_INST_BVH2(2, 1, false) RT_INST_BVH2(2, 1, true)
+#define RT_INST_BVH2L(P, T) template __global__ void k_extend_bvh2<0, P, T, true>(BvhView, RayQ, const uint32_t*, uint64_t, double, double, ExtendOut, StackEntry*, uint32_t*, uint32_t, unsigned long long*, unsigned long long*);
+RT_INST_BVH2L(0, false) RT_INST_BVH2L(0, true) RT_INST_BVH2L(2, false) RT_INST_BVH2L(2, true)
 
 // extend_naive: HittableList::hit, naive arm (hittable_list.rs:67-80): every object in file order.
 // per-triangle constants of hit_triangle_pre (all-triangle scenes only)

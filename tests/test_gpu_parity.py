@@ -589,3 +589,60 @@ def test_cooperative_grid_cells_bit_exact(gpu, monkeypatch, seed, n, spread, gri
     assert np.array_equal(np.isfinite(img), fin)
     assert np.max(np.abs(img[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300), initial=0.0) <= RADIANCE_RTOL
     w.close()
+
+
+@pytest.mark.parametrize("scene,bvh_mode", [("weekend-final", "sah-position"), ("weekend-final", "naive"), ("weekend-final", "sah-plane"),
+                                            ("weekend-5-80-15", "sah-position"), ("simple_hollow_glass", "sah-position"),
+                                            ("mixed", "sah-position"), ("mixed", "naive")])
+def test_lds_resident_tree_bit_exact(gpu, monkeypatch, scene, bvh_mode):
+    """k_extend_bvh2<0, P, T, LDS>: a small scene's pair and primitive tables staged in LDS by 1024-thread workgroups, four
+    continuation-stack entries per lane in LDS (the rest in HBM).  By default only queues of >= 65 536 rays take it;
+    RT_LDS_TREE=3 sends every queue through it and fails the call if the scene does not qualify.  Same traces, counters and
+    image as the oracle: all-sphere (48-byte records) and mixed (80-byte records) scenes, deep `naive` trees (stack spills),
+    degenerate rays, both interval ends finite."""
+    import raytracer_amd as rt
+    w = weekend_mixed() if scene == "mixed" else load_world(scene)
+    osc = setup_pair(w, "bvh", bvh_mode)
+    w.upload()
+    try:
+        monkeypatch.setenv("RT_LDS_TREE", "3"); rt.init(0)
+        cam = Camera(w.filename, image_width=200)
+        pi, pj = primary_rays(cam)
+        o, d = cam.get_rays(pi, pj, sample=0, seed=3)
+        assert_trace_equal(w.hit(o, d), osc.trace("bvh", o, d), f"lds {scene}/{bvh_mode} primary")
+        ro, rd = random_rays(70000, 19, -15.0, 25.0)
+        assert_trace_equal(w.hit(ro, rd, 0.001, 1e9), osc.trace("bvh", ro, rd, 0.001, 1e9), f"lds {scene}/{bvh_mode} random")
+        assert_trace_equal(w.hit(ro[:20000], rd[:20000], 0.001, 4.0), osc.trace("bvh", ro[:20000], rd[:20000], 0.001, 4.0), f"lds {scene}/{bvh_mode} tmax 4")
+        eo, ed = _edge_rays(w, 4000, 77)
+        with np.errstate(all="ignore"):
+            assert_trace_equal(w.hit(eo, ed), osc.trace("bvh", eo, ed), f"lds {scene}/{bvh_mode} degenerate")
+        cam = Camera(w.filename, image_width=128, samples_per_pixel=4, max_depth=50)
+        img, st = cam.render(w, seed=5)
+    finally:
+        monkeypatch.delenv("RT_LDS_TREE"); rt.init(0)
+    ref, cst = osc.render(O.camera_from_rt(cam.c), "bvh", 0, 4, 50, seed=5, nthreads=8)
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb"):
+        assert st[k] == cst[k], f"counter {k}: gpu {st[k]} oracle {cst[k]}"
+    assert np.max(np.abs(img - ref) / np.maximum(np.abs(ref), 1e-300)) <= RADIANCE_RTOL
+    # and the default launch rule (this queue length keeps the 128-thread kernel) gives the same bits
+    img2, st2 = cam.render(w, seed=5)
+    assert np.array_equal(bits(img), bits(img2))
+    for k in ("primary_rays", "scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb", "box_tests", "prim_tests", "ray_segments"):
+        assert st2[k] == st[k], k
+    w.close()
+
+
+def test_lds_resident_tree_refuses_lattice_scenes(gpu, monkeypatch):
+    """RT_LDS_TREE=3 is the tests' way to know which kernel ran: a scene that does not qualify (f32-lattice triangles keep the
+    64-byte pairs in HBM) must fail the call, not fall back silently."""
+    import raytracer_amd as rt
+    w = load_world("dragon_res4"); w.algorithm = "bvh"; w.init().upload()
+    ro, rd = random_rays(1000, 1, -15.0, 25.0)
+    try:
+        monkeypatch.setenv("RT_LDS_TREE", "3"); rt.init(0)
+        with pytest.raises(rt.RtError, match="RT_LDS_TREE=3"):
+            w.hit(ro, rd)
+    finally:
+        monkeypatch.delenv("RT_LDS_TREE"); rt.init(0)
+    assert w.hit(ro, rd)["hit"].shape == (1000,)
+    w.close()
