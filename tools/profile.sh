@@ -20,4 +20,5 @@ run tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
 run fetch --pmc FETCH_SIZE || exit 1
 run write --pmc WRITE_SIZE || exit 1
 run sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_FLAT || echo "sq2 failed (optional)"
+run lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT || echo "lds failed (optional)"
 find $OUT -name "*.csv" | head -50
