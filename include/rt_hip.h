@@ -102,9 +102,15 @@ int rt_scene_set_options(rt_scene*, uint32_t flags);
 /* Replaces Bvh::new (src/acceleration/bvh.rs:19-180) for the default BvhSahPosition mode, on the GPU: the same nodes
  * (indices 0..=node_pointer, bvh.rs:14-15), numbering and object permutation (bvh.rs:13) as the reference's top-down SAH
  * build.  prims/centroids are host arrays (centroid = Hittable::centroid(), n*3 doubles); nodes_out must hold 2*n_prims
- * nodes, order_out n_prims indices.  The other build modes (-o bvh-naive, -o bvh-sah-plane) stay on the host. */
+ * nodes, order_out n_prims indices. */
 int rt_bvh_build(const rt_prim* prims, const double* centroids, uint32_t n_prims,
                  rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out);
+/* The same for any AlgorithmOptions build mode (rtweekend.rs:137-147; get_split bvh.rs:86-142): RT_BVH_SAH_POSITION (the default,
+ * every split position of every axis, bvh.rs:124-133), RT_BVH_SAH_PLANE (`-o bvh-sah-plane`: the median of each axis, bvh.rs:114-123),
+ * RT_BVH_NAIVE (`-o bvh-naive`: median of the x order for nodes of >= 3 objects, bvh.rs:87-99). */
+enum { RT_BVH_SAH_POSITION = 0, RT_BVH_SAH_PLANE = 1, RT_BVH_NAIVE = 2 };
+int rt_bvh_build_mode(const rt_prim* prims, const double* centroids, uint32_t n_prims, int mode,
+                      rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out);
 
 /* Replaces HittableList.grid = Grid::new(...) (hittable_list.rs:43, grid.rs:23-61) entirely on the GPU: bins the scene's
  * objects into the fixed [-100,100]^3 grid of cell size `grid_size` with the reference's table layout (get_index slots,

@@ -61,7 +61,7 @@ class RtStats(C.Structure):
 RT_COMM_ID_BYTES = 128
 
 # every symbol include/rt_hip.h declares (tests check the library exports exactly these)
-RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_scene_build_grid", "rt_scene_get_grid", "rt_trace",
+RT_HIP_SYMBOLS = ["rt_init", "rt_set_profiling", "rt_scene_create", "rt_scene_set_bvh", "rt_scene_set_grid", "rt_scene_set_options", "rt_scene_bvh_layout", "rt_bvh_build", "rt_bvh_build_mode", "rt_scene_build_grid", "rt_scene_get_grid", "rt_trace",
                   "rt_generate", "rt_render", "rt_render_device", "rt_render_device_noalloc", "rt_scene_reserve", "rt_scene_destroy", "rt_last_error",
                   "rt_comm_unique_id", "rt_comm_create", "rt_comm_reduce_sum", "rt_comm_destroy", "rt_render_reduce"]
 
@@ -92,6 +92,7 @@ def hip_lib():
     lib.rt_scene_set_grid.argtypes = [C.c_void_p, P(RtGridDesc), P(C.c_double), P(C.c_uint64), P(C.c_uint32)]; lib.rt_scene_set_grid.restype = C.c_int
     lib.rt_scene_set_options.argtypes = [C.c_void_p, C.c_uint32]; lib.rt_scene_set_options.restype = C.c_int
     lib.rt_bvh_build.argtypes = [P(RtPrim), C.c_void_p, C.c_uint32, P(RtBvhNode), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]; lib.rt_bvh_build.restype = C.c_int
+    lib.rt_bvh_build_mode.argtypes = [P(RtPrim), C.c_void_p, C.c_uint32, C.c_int, P(RtBvhNode), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]; lib.rt_bvh_build_mode.restype = C.c_int
     lib.rt_scene_build_grid.argtypes = [C.c_void_p, C.c_double]; lib.rt_scene_build_grid.restype = C.c_int
     lib.rt_scene_get_grid.argtypes = [C.c_void_p, P(RtGridDesc), P(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p]; lib.rt_scene_get_grid.restype = C.c_int
     lib.rt_scene_bvh_layout.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32)]; lib.rt_scene_bvh_layout.restype = C.c_int
@@ -140,7 +141,7 @@ def host_lib():
     lib.rth_scene_centroids.argtypes = [C.c_void_p]; lib.rth_scene_centroids.restype = P(C.c_double)
     lib.rth_scene_mats.argtypes = [C.c_void_p]; lib.rth_scene_mats.restype = P(RtMaterial)
     lib.rth_bvh_build.argtypes = [C.c_void_p, C.c_int]; lib.rth_bvh_build.restype = C.c_void_p
-    lib.rth_bvh_build_gpu.argtypes = [C.c_void_p]; lib.rth_bvh_build_gpu.restype = C.c_void_p
+    lib.rth_bvh_build_gpu.argtypes = [C.c_void_p, C.c_int]; lib.rth_bvh_build_gpu.restype = C.c_void_p
     lib.rth_bvh_free.argtypes = [C.c_void_p]; lib.rth_bvh_free.restype = None
     lib.rth_bvh_n_nodes.argtypes = [C.c_void_p]; lib.rth_bvh_n_nodes.restype = C.c_uint32
     lib.rth_bvh_depth.argtypes = [C.c_void_p]; lib.rth_bvh_depth.restype = C.c_uint32

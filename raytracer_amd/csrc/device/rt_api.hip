@@ -16,7 +16,7 @@
 #include <vector>
 
 namespace rtb {   // rt_build.hip
-int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+int build(const rt_prim* prims, const double* centroids, uint32_t n, int mode, rt_bvh_node* nodes_out, uint32_t* n_nodes_out,
           uint32_t* order_out, uint32_t* depth_out, hipStream_t st, std::string& err);
 struct GridResult { rt_grid_desc desc; double* cell_aabb; unsigned long long* cell_offset; uint32_t* prim_list; unsigned long long list_len; };
 int build_grid(const rt_prim* prims, uint32_t n, double s, GridResult& out, hipStream_t st, std::string& err);
@@ -575,11 +575,17 @@ int rt_scene_set_options(rt_scene* sc, uint32_t flags) {
 
 int rt_bvh_build(const rt_prim* prims, const double* centroids, uint32_t n_prims,
                  rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out) {
+    return rt_bvh_build_mode(prims, centroids, n_prims, RT_BVH_SAH_POSITION, nodes_out, n_nodes_out, order_out, depth_out);
+}
+
+int rt_bvh_build_mode(const rt_prim* prims, const double* centroids, uint32_t n_prims, int mode,
+                      rt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* depth_out) {
     if (!g_inited) return fail(RT_E_STATE, "rt_init() has not been called");
     if (!prims || !centroids || !nodes_out || !n_nodes_out || !order_out || !depth_out) return fail(RT_E_ARG, "null argument");
     for (uint32_t i = 0; i < n_prims; ++i) if (prims[i].type > RT_TRIANGLE) return fail(RT_E_ARG, "primitive %u has unknown type %u", i, prims[i].type);
     std::string err;
-    const int rc = rtb::build(prims, centroids, n_prims, nodes_out, n_nodes_out, order_out, depth_out, g_stream, err);
+    if (mode < RT_BVH_SAH_POSITION || mode > RT_BVH_NAIVE) return fail(RT_E_ARG, "unknown BVH build mode %d", mode);
+    const int rc = rtb::build(prims, centroids, n_prims, mode, nodes_out, n_nodes_out, order_out, depth_out, g_stream, err);
     if (rc != RT_OK) return fail(rc, "%s", err.c_str());
     return RT_OK;
 }

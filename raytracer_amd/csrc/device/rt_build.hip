@@ -1,4 +1,6 @@
-// rt_build.hip — Bvh::new (src/acceleration/bvh.rs:19-180) on the GPU for the default `BvhSahPosition` mode, producing the
+// rt_build.hip — Bvh::new (src/acceleration/bvh.rs:19-180) on the GPU for all three build modes (`BvhSahPosition`, the default,
+// described below; `BvhSahPlane` = the same with the median as the only candidate of an axis, bvh.rs:114-123; `BvhNaive` = median
+// split of the x-sorted slice for nodes of >= 3 objects, no cost, bvh.rs:87-99), producing the
 // same tree, node numbering and object order as the reference (and as the host builder in host/accel.cpp, which the tests
 // compare it with byte for byte).
 //
@@ -111,13 +113,14 @@ __global__ void k_gather_boxes(const Box6* __restrict__ boxes, const uint32_t* _
     fwd[i] = b; rev[M - 1 - i] = b; rev_seg[M - 1 - i] = segidx[i];
 }
 // cost of splitting segment s before dense position i (bvh.rs:152-154); position `base` of a segment is no candidate
+// (median_only: BvhSahPlane evaluates the one position len/2 per axis, bvh.rs:114-123)
 __global__ void k_cost(const Box6* __restrict__ pre, const Box6* __restrict__ suf_rev, const uint32_t* __restrict__ segidx,
-                       const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_count, uint32_t M, Cand* __restrict__ cand) {
+                       const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_count, uint32_t M, bool median_only, Cand* __restrict__ cand) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const uint32_t s = segidx[i], j = i - seg_base[s], n = seg_count[s];
     Cand c; c.pos = i; c.pad = 0; c.key = RTB_NOCAND;
-    if (j >= 1) {
+    if (j >= 1 && (!median_only || j == n / 2)) {
         const double h = area(pre[i - 1]) * (double)j + area(suf_rev[M - 1 - i]) * (double)(n - j);
         c.key = cost_key(h);
     }
@@ -130,10 +133,11 @@ struct NodeArrays {           // creation-order node table (capacity 2N)
 // one thread per segment: the winner over the three axes in the reference's order, strict `<` (bvh.rs:101,127)
 __global__ void k_decide(uint32_t S, const uint32_t* __restrict__ seg_node, const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_count,
                          const Cand* __restrict__ best0, const Cand* __restrict__ best1, const Cand* __restrict__ best2,
-                         NodeArrays nodes, uint32_t* __restrict__ best_axis, uint32_t* __restrict__ split, uint32_t* __restrict__ is_split) {
+                         NodeArrays nodes, bool naive, uint32_t* __restrict__ best_axis, uint32_t* __restrict__ split, uint32_t* __restrict__ is_split) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const uint32_t base = seg_base[s], n = seg_count[s], last = base + n - 1;
+    if (naive) { best_axis[s] = 0; split[s] = n / 2; is_split[s] = 1u; return; }        // bvh.rs:87-99: every node of >= 3 objects (the only active ones) splits at its median
     const Box6 nb = nodes.box[seg_node[s]];
     double best = area(nb) * (double)n;                                   // bvh.rs:101
     uint32_t ax = 0, sp = 0;
@@ -155,13 +159,14 @@ __global__ void k_apply_order(uint32_t M, const uint32_t* __restrict__ segidx, c
     order[seg_first[s] + (i - seg_base[s])] = a == 0 ? s0[i] : (a == 1 ? s1[i] : s2[i]);
 }
 // children of the segments that split (BvhNode::sub_divide bvh.rs:162-180): node records, and the flags / sizes of the next
-// level's segments (children with fewer than two objects can never split: get_split has no candidate for them)
+// level's segments (children with fewer than two objects can never split: get_split has no candidate for them; BvhNaive
+// leaves nodes of fewer than three alone, slice order included: bvh.rs:88-90)
 __global__ void k_children(uint32_t S, const uint32_t* __restrict__ seg_node, const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_first,
                            const uint32_t* __restrict__ seg_count, const uint32_t* __restrict__ best_axis, const uint32_t* __restrict__ split,
                            const uint32_t* __restrict__ split_rank, uint32_t node_base, uint32_t M,
                            const Box6* __restrict__ pre0, const Box6* __restrict__ pre1, const Box6* __restrict__ pre2,
                            const Box6* __restrict__ suf0, const Box6* __restrict__ suf1, const Box6* __restrict__ suf2,
-                           NodeArrays nodes, uint32_t* __restrict__ child_active, uint32_t* __restrict__ child_count) {
+                           NodeArrays nodes, uint32_t min_active, uint32_t* __restrict__ child_active, uint32_t* __restrict__ child_count) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const uint32_t sp = split[s];
@@ -172,8 +177,8 @@ __global__ void k_children(uint32_t S, const uint32_t* __restrict__ seg_node, co
     nodes.left[seg_node[s]] = l;
     nodes.first[l] = seg_first[s]; nodes.count[l] = sp; nodes.box[l] = pre[base + sp - 1]; nodes.left[l] = 0;
     nodes.first[r] = seg_first[s] + sp; nodes.count[r] = n - sp; nodes.box[r] = suf[M - 1 - (base + sp)]; nodes.left[r] = 0;
-    child_active[2 * j] = sp >= 2 ? 1u : 0u; child_count[2 * j] = sp >= 2 ? sp : 0u;
-    child_active[2 * j + 1] = (n - sp) >= 2 ? 1u : 0u; child_count[2 * j + 1] = (n - sp) >= 2 ? (n - sp) : 0u;
+    child_active[2 * j] = sp >= min_active ? 1u : 0u; child_count[2 * j] = sp >= min_active ? sp : 0u;
+    child_active[2 * j + 1] = (n - sp) >= min_active ? 1u : 0u; child_count[2 * j + 1] = (n - sp) >= min_active ? (n - sp) : 0u;
 }
 // compact the active children into the next level's segment table
 __global__ void k_next_segments(uint32_t n_children, uint32_t node_base, const uint32_t* __restrict__ child_active, const uint32_t* __restrict__ child_slot,
@@ -214,9 +219,13 @@ struct DevBuf {
 #define RTB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + " failed: " + hipGetErrorString(e_); return RT_E_HIP; } } while (0)
 #define RTB_ALLOC(ptr, T, n) do { ptr = buf.get<T>(n); if (!ptr) { err = "out of device memory in the BVH build"; return RT_E_HIP; } } while (0)
 
-int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+int build(const rt_prim* prims, const double* centroids, uint32_t n, int mode, rt_bvh_node* nodes_out, uint32_t* n_nodes_out,
           uint32_t* order_out, uint32_t* depth_out, hipStream_t st, std::string& err) {
     if (n == 0) { err = "scene has no objects"; return RT_E_ARG; }
+    if (mode < RT_BVH_SAH_POSITION || mode > RT_BVH_NAIVE) { err = "unknown BVH build mode"; return RT_E_ARG; }
+    const bool naive = mode == RT_BVH_NAIVE, median_only = mode == RT_BVH_SAH_PLANE;
+    const uint32_t min_active = naive ? 3u : 2u;         // the smallest node get_split can split
+    const int n_axes = naive ? 1 : 3;
     if (n > 0x3fffffffu) { err = "too many objects"; return RT_E_LIMIT; }
     DevBuf buf;
     const uint32_t TB = 256;
@@ -277,14 +286,14 @@ int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node
         RTB_CHECK(hipStreamSynchronize(st));
     }
 
-    uint32_t S = n >= 2 ? 1u : 0u, M = n >= 2 ? n : 0u, n_nodes = 1;
+    uint32_t S = n >= min_active ? 1u : 0u, M = n >= min_active ? n : 0u, n_nodes = 1;
     int cur = 0;
     for (uint32_t level = 0; S > 0; ++level) {
         if (level > 4096) { err = "BVH deeper than 4096 levels"; return RT_E_LIMIT; }
         const uint32_t *sn = seg_node[cur], *sf = seg_first[cur], *sc = seg_count[cur], *sb = seg_base[cur];
         hipLaunchKernelGGL(k_dense, blocks(M), dim3(TB), 0, st, sb, sf, S, M, order, segidx, obj);
         int seg_bits = 1; while ((1ull << seg_bits) < S) ++seg_bits;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < n_axes; ++a) {
             hipLaunchKernelGGL(k_keys, blocks(M), dim3(TB), 0, st, akey[a], obj, segidx, M, key_a, val_a);
             size_t tb = tmp_bytes;
             RTB_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_a, key_b, val_a, val_b, (int)M, 0, 64, st));
@@ -300,11 +309,12 @@ int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node
             RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, segidx, fwd, pre[a], BoxUnion(), (int)M, SegEq(), st));
             tb = tmp_bytes;
             RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, rev_seg, rev, suf[a], BoxUnionRev(), (int)M, SegEq(), st));
-            hipLaunchKernelGGL(k_cost, blocks(M), dim3(TB), 0, st, pre[a], suf[a], segidx, sb, sc, M, cand);
+            if (naive) continue;                         // no cost: the median of the x order
+            hipLaunchKernelGGL(k_cost, blocks(M), dim3(TB), 0, st, pre[a], suf[a], segidx, sb, sc, M, median_only, cand);
             tb = tmp_bytes;
             RTB_CHECK(hipcub::DeviceScan::InclusiveScanByKey(tmp, tb, segidx, cand, best[a], CandMin(), (int)M, SegEq(), st));
         }
-        hipLaunchKernelGGL(k_decide, blocks(S), dim3(TB), 0, st, S, sn, sb, sc, best[0], best[1], best[2], nodes, best_axis, split, is_split);
+        hipLaunchKernelGGL(k_decide, blocks(S), dim3(TB), 0, st, S, sn, sb, sc, best[0], best[1], best[2], nodes, naive, best_axis, split, is_split);
         hipLaunchKernelGGL(k_apply_order, blocks(M), dim3(TB), 0, st, M, segidx, sb, sf, best_axis, sorted[0], sorted[1], sorted[2], order);
         // ranks of the splitting segments (+ their number in the extra element)
         RTB_CHECK(hipMemsetAsync(is_split + S, 0, sizeof(uint32_t), st));
@@ -319,7 +329,7 @@ int build(const rt_prim* prims, const double* centroids, uint32_t n, rt_bvh_node
         RTB_CHECK(hipMemsetAsync(child_active, 0, ((size_t)n_children + 1) * sizeof(uint32_t), st));
         RTB_CHECK(hipMemsetAsync(child_count, 0, ((size_t)n_children + 1) * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_children, blocks(S), dim3(TB), 0, st, S, sn, sb, sf, sc, best_axis, split, split_rank, n_nodes, M,
-                           pre[0], pre[1], pre[2], suf[0], suf[1], suf[2], nodes, child_active, child_count);
+                           pre[0], pre[1], pre[2], suf[0], suf[1], suf[2], nodes, min_active, child_active, child_count);
         tb = tmp_bytes;
         RTB_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, child_active, child_slot, (int)n_children + 1, st));
         tb = tmp_bytes;

@@ -475,6 +475,11 @@ __global__ __launch_bounds__(LDS ? RT_LBLOCK : RT_BLOCK, RT_WAVES_PER_EU) void k
                     // record (another cache line half of the time); the value is consumed by an empty asm so the load stays
                     for (int e = 0; e < RT_PROBE_L1; ++e) { uint4 x = pp[-1 - e]; /* the previous record (pair indices start at 1): in bounds */ asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
 #endif
+#ifdef RT_PROBE_L1SAME
+                    // sensitivity probe: RT_PROBE_L1SAME more 16-byte lane accesses per visit to the record just read (the same cache line:
+                    // L1 hits by construction) -- separates the cost of a lane access from the cost of touching another line
+                    for (int e = 0; e < RT_PROBE_L1SAME; ++e) { typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); const u32x4 x = *(const volatile __attribute__((address_space(1))) u32x4*)(uintptr_t)(pp + (3 - (e & 3))); asm volatile("" :: "v"(x)); }
+#endif
 #ifdef RT_PROBE_VALU
                     // sensitivity probe: RT_PROBE_VALU more 32-bit VALU instructions per visit (the v_bfe_i32 / v_bfi_b32 / v_cndmask
                     // mix a 48-byte "new planes + selector bits" record would need to rebuild the two boxes)

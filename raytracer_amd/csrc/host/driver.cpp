@@ -185,12 +185,12 @@ int render_slice(const Cli& cli, const Scene& scene, const Accel& acc, const rt_
     if (cli.algorithm == RT_ALGO_BVH) {
         if (acc.have_bvh) {
             if (rt_scene_set_bvh(dev, acc.bvh.nodes.data(), (uint32_t)acc.bvh.nodes.size(), acc.bvh.order.data(), (uint32_t)acc.bvh.order.size()) != RT_OK) return fail_hip();
-        } else {                                         // --gpu-build, default SAH mode
+        } else {                                         // --gpu-build (any build mode)
             auto t = std::chrono::steady_clock::now();
             Bvh bvh; const uint32_t n = (uint32_t)scene.prims.size();
             bvh.nodes.resize(2 * (size_t)n + 1); bvh.order.resize(n);
             uint32_t n_nodes = 0;
-            if (rt_bvh_build(scene.prims.data(), scene.centroids.data(), n, bvh.nodes.data(), &n_nodes, bvh.order.data(), &bvh.depth) != RT_OK) return fail_hip();
+            if (rt_bvh_build_mode(scene.prims.data(), scene.centroids.data(), n, (int)bvh_mode_of(cli.options), bvh.nodes.data(), &n_nodes, bvh.order.data(), &bvh.depth) != RT_OK) return fail_hip();
             bvh.nodes.resize(n_nodes);
             if (rt_scene_set_bvh(dev, bvh.nodes.data(), n_nodes, bvh.order.data(), n) != RT_OK) return fail_hip();
             fprintf(stderr, "BVH constructed in %.2fs (%zu nodes, depth %u)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(), bvh.nodes.size(), bvh.depth);
@@ -264,7 +264,7 @@ int run(const Cli& cli, RunStats* stats_out, std::string& err) {
     auto start = std::chrono::steady_clock::now();
     // world.init() main.rs:128 → hittable_list.rs:33-53, host part: the builders run once, before any worker exists
     Accel acc;
-    if (cli.algorithm == RT_ALGO_BVH && !(cli.gpu_build && bvh_mode_of(cli.options) == BVH_SAH_POSITION)) {
+    if (cli.algorithm == RT_ALGO_BVH && !cli.gpu_build) {
         auto t = std::chrono::steady_clock::now();
         if (!build_bvh(scene, bvh_mode_of(cli.options), acc.bvh, err)) return 1;
         acc.have_bvh = true;

@@ -29,7 +29,7 @@ struct Cli {                                                                // r
                                         // N > 1 and every worker has a GPU of its own, host otherwise (workers sharing one GPU cannot form a communicator)
     int subdivide = 0;                  // synthetic refinement levels for PLY meshes (not a reference feature)
     std::string output_dir = "output";
-    bool gpu_build = false;             // --gpu-build: Bvh::new (default SAH mode) / Grid::new on the GPU
+    bool gpu_build = false;             // --gpu-build: Bvh::new (any build mode) / Grid::new on the GPU
     bool binary_ppm = false;            // --binary-ppm: write P6 instead of the reference's P3 text (addition)
 };
 

@@ -51,14 +51,14 @@ void* rth_bvh_build(const void* scene, int mode) {
     if (!build_bvh(*(const Scene*)scene, (BvhMode)mode, *b, g_err)) { delete b; return nullptr; }
     return b;
 }
-// Bvh::new on the GPU (rt_bvh_build, BvhSahPosition only): same Bvh object as the host builder returns
-void* rth_bvh_build_gpu(const void* scene) {
+// Bvh::new on the GPU (rt_bvh_build_mode): same Bvh object as the host builder returns
+void* rth_bvh_build_gpu(const void* scene, int mode) {
     const Scene& sc = *(const Scene*)scene;
     Bvh* b = new Bvh();
     const uint32_t n = (uint32_t)sc.prims.size();
     b->nodes.resize(2 * (size_t)n + 1); b->order.resize(n);
     uint32_t n_nodes = 0, depth = 0;
-    if (rt_bvh_build(sc.prims.data(), sc.centroids.data(), n, b->nodes.data(), &n_nodes, b->order.data(), &depth) != RT_OK) {
+    if (rt_bvh_build_mode(sc.prims.data(), sc.centroids.data(), n, mode, b->nodes.data(), &n_nodes, b->order.data(), &depth) != RT_OK) {
         g_err = rt_last_error(); delete b; return nullptr;
     }
     b->nodes.resize(n_nodes); b->depth = depth;

@@ -108,7 +108,7 @@ class HittableList:
         self.bvh_mode = "sah-position"
         self.grid_size = 25.0
         self.draw_boxes = False          # Options.draw_boxes (rtweekend.rs:92), `-o draw-boxes`
-        self.gpu_build = False           # build the SAH-position BVH / the grid on the GPU (rt_bvh_build, rt_scene_build_grid)
+        self.gpu_build = False           # build the BVH (any mode) / the grid on the GPU (rt_bvh_build_mode, rt_scene_build_grid)
         self.bvh = None
         self.grid = None
         self._dev = None
@@ -159,9 +159,9 @@ class HittableList:
     def init(self):
         lib = F.host_lib()
         if self.algorithm == "bvh":
-            if self.gpu_build and self.bvh_mode == "sah-position":
+            if self.gpu_build:
                 F.hip_lib()
-                h = lib.rth_bvh_build_gpu(self._h)
+                h = lib.rth_bvh_build_gpu(self._h, self.BVH_MODES[self.bvh_mode])
             else:
                 h = lib.rth_bvh_build(self._h, self.BVH_MODES[self.bvh_mode])
             if not h:

@@ -1,4 +1,4 @@
-"""Bvh::new on the GPU (rt_bvh_build) against the host builder and against the oracle (its literal
+"""Bvh::new on the GPU (rt_bvh_build / rt_bvh_build_mode) against the host builder and against the oracle (its literal
 restatement of bvh.rs:19-180 up to res4, its sweep form above that — tests/test_oracle_sweep.py): nodes, numbering and object
 order byte for byte."""
 import time
@@ -13,8 +13,8 @@ from .util import load_world, oracle_of, weekend_mixed
 pytestmark = pytest.mark.gpu
 
 
-def both(w):
-    w.algorithm, w.bvh_mode = "bvh", "sah-position"
+def both(w, mode="sah-position"):
+    w.algorithm, w.bvh_mode = "bvh", mode
     w.gpu_build = False; w.init(); host = (w.bvh.nodes().copy(), w.bvh.order(len(w)).copy(), w.bvh.depth)
     w.gpu_build = True; t = time.time(); w.init(); dt = time.time() - t
     return host, (w.bvh.nodes().copy(), w.bvh.order(len(w)).copy(), w.bvh.depth), dt
@@ -33,6 +33,45 @@ def test_gpu_bvh_equals_host_bvh(gpu, scene):
     assert dev[0].tobytes() == host[0].tobytes(), "box planes differ"
     on, oo = oracle_of(w).build_bvh("sah-position", sweep=scene == "dragon_res3").get_bvh()
     assert on.tobytes() == dev[0].tobytes() and np.array_equal(oo, dev[1]), "GPU-built tree differs from the oracle's"
+
+
+@pytest.mark.parametrize("mode", ["sah-plane", "naive"])
+@pytest.mark.parametrize("scene", ["simple_fuzzy_metal", "triangle_test", "triangle_materials", "weekend-5-80-15", "weekend-final", "mixed",
+                                   "dragon_res4", "dragon_res3"])
+def test_gpu_bvh_other_modes_equal_host_and_oracle(gpu, scene, mode):
+    """rt_bvh_build_mode for `-o bvh-sah-plane` (bvh.rs:114-123) and `-o bvh-naive` (bvh.rs:87-99): nodes, numbering and object
+    order byte for byte as the host builder's and the oracle's literal builder's (which stays cheap in these modes: one
+    candidate per axis / none)."""
+    w = weekend_mixed() if scene == "mixed" else load_world(scene)
+    host, dev, _ = both(w, mode)
+    assert dev[2] == host[2] and len(dev[0]) == len(host[0])
+    assert np.array_equal(dev[1], host[1]), f"object order differs at {np.flatnonzero(dev[1] != host[1])[:8]}"
+    assert dev[0].tobytes() == host[0].tobytes()
+    on, oo = oracle_of(w).build_bvh(mode).get_bvh()
+    assert on.tobytes() == dev[0].tobytes() and np.array_equal(oo, dev[1]), "GPU-built tree differs from the oracle's"
+
+
+@pytest.mark.parametrize("mode", ["sah-plane", "naive"])
+def test_gpu_bvh_other_modes_small_and_adversarial(gpu, mode):
+    """Node sizes around the modes' thresholds (naive leaves nodes of < 3 objects alone, order included), duplicate centroids,
+    signed zeros."""
+    from oracle.oracle_py import OracleScene
+    dt = [("type", "<u4"), ("material", "<u4"), ("v", "<f8", (9,))]
+    mats = np.zeros(1, dtype=[("type", "<u4"), ("pad", "<u4"), ("albedo", "<f8", (3,)), ("param", "<f8")])
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 33, 600):
+        p = np.zeros(n, dtype=dt); p["type"] = 1
+        grid = rng.integers(-3, 4, size=(n, 3)).astype(np.float64)
+        v = grid[:, None, :] + rng.choice([0.0, -0.0, 0.5, 1.0], size=(n, 3, 3))
+        v[::3] = np.where(v[::3] == 0.0, -0.0, v[::3])
+        p["v"] = v.reshape(n, 9)
+        cent = np.round(v.mean(axis=1))[::-1].copy()         # descending-ish x: the sort has work to do, ties abound
+        w = HittableList.from_arrays(p, cent, mats)
+        host, dev, _ = both(w, mode)
+        on, oo = OracleScene(w.prims(), w.centroids(), w.materials()).build_bvh(mode).get_bvh()
+        assert np.array_equal(dev[1], oo) and np.array_equal(host[1], oo), f"n={n}: object order"
+        assert host[0].tobytes() == on.tobytes(), f"n={n}: host vs oracle"
+        assert dev[0].tobytes() == on.tobytes(), f"n={n}: GPU vs oracle"
 
 
 def test_gpu_bvh_single_object_and_duplicates(gpu):

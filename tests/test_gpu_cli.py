@@ -85,6 +85,19 @@ def test_gpu_built_grid_gives_the_same_image(gpu, tmp_path):
         assert ra[k] == rb[k], k
 
 
+@pytest.mark.parametrize("opt,name", [("bvh-naive", "weekend-final-bvh-BvhNaive.ppm"), ("bvh-sah-plane", "weekend-final-bvh-BvhSahPlane.ppm")])
+def test_gpu_built_bvh_modes_give_the_same_image(gpu, tmp_path, opt, name):
+    """--gpu-build with `-o bvh-naive` / `-o bvh-sah-plane` (rt_bvh_build_mode): the same tree as the host builder's, hence the same
+    pixels and counters."""
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    base = ["scenes/weekend-final.json", "--width", "96", "--spp", "2", "-o", opt]
+    assert rt.run(base + ["--output-dir", a]) == 0 and rt.run(base + ["--output-dir", b, "--gpu-build"]) == 0
+    assert open(os.path.join(a, name)).read() == open(os.path.join(b, name)).read()
+    ra, rb = (list(csv.DictReader(open(os.path.join(d, "stats.csv"))))[0] for d in (a, b))
+    for k in ("intersection_checks", "traversal_steps", "overlapping_aabb", "scatter_rays"):
+        assert ra[k] == rb[k], k
+
+
 def test_cli_gpus_2_equals_gpus_1(gpu, tmp_path):
     """`raytracer --gpus N` (the host adds --gpus): N forked workers, each rendering its spp_range, partial sums
     added in rank order by the parent.  Here N = 2 on the box's one GPU (--device 0 makes every worker use it); the image
