@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--reduce", default="torch", choices=["torch", "product"],
                     help="the per-step framebuffer reduce: torch.distributed.reduce (RCCL through torch; default) or the product library's own "
                          "communicator (rt_comm_reduce_sum = ncclReduce; also exercised at N = 1)")
+    ap.add_argument("--dist-at-1", action="store_true", help="rehearsal: with --gpus 1 under a launcher, still create the process group and run every "
+                    "collective of the N > 1 path (init, warm-up all-reduce, the framebuffer reduce, barrier, the MAX / SUM all-reduces) over one rank")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that feed the roofline")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the profiled re-run: one step, counters only
     return ap.parse_args()
@@ -104,7 +106,8 @@ def main():
     if a.force_device >= 0:
         local_rank = a.force_device
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.dist_at_1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -132,14 +135,14 @@ def main():
     # set-up that is not a step: the render workspace (one hipMalloc set of ~200 GB at the default size) and the communicator's
     # first collective, so that a run with --warmup 0 times steps and nothing else
     cam.reserve(w, s_count)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"))
     torch.cuda.synchronize()
 
     comm = None
     if a.reduce == "product":                                 # the library's own RCCL communicator (include/rt_hip.h rt_comm_*)
         ids = [rt.Comm.unique_id() if rank == 0 else None]
-        if world > 1:
+        if use_dist:
             dist.broadcast_object_list(ids, src=0)
         comm = rt.Comm(ids[0], world, rank)
 
@@ -148,11 +151,11 @@ def main():
         if comm is not None:
             comm.reduce_sum(fb.data_ptr(), fb.numel(), root=0, stream=stream)
         else:
-            reduce_framebuffer(fb, dst=0)                    # RCCL over xGMI: the one exchange step of the path
+            reduce_framebuffer(fb, dst=0, force=a.dist_at_1)    # RCCL over xGMI: the one exchange step of the path
         return st
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +189,7 @@ def main():
         rt.set_profiling(False)
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     rays = torch.tensor([float(agg["primary_rays"] + agg["scatter_rays"])], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     dt = float(tt.item()); total_rays = float(rays.item())
@@ -232,7 +235,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, cam_name, a)
             out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,9 +12,10 @@ def spp_range(rank, world_size, spp_total):
     return begin, base + (1 if rank < rem else 0)
 
 
-def reduce_framebuffer(fb, dst=0):
-    """Sum the per-rank framebuffers (a torch tensor, any device) onto rank `dst`; no-op for a single process."""
+def reduce_framebuffer(fb, dst=0, force=False):
+    """Sum the per-rank framebuffers (a torch tensor, any device) onto rank `dst`; no-op for a single process unless `force`
+    (a one-rank rehearsal of the collective: the sum over one rank is the identity)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb

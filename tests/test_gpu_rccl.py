@@ -70,3 +70,22 @@ def test_cli_rccl_refuses_workers_that_share_a_gpu(gpu, tmp_path):
     r = subprocess.run([exe, "scenes/simple_fuzzy_metal.json", "--width", "32", "--spp", "2", "--gpus", "2", "--device", "0", "--reduce", "rccl",
                         "--output-dir", str(tmp_path / "o")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "one GPU per worker" in (r.stderr + r.stdout)
+
+
+def test_bench_runs_every_collective_of_the_multi_gpu_path_over_one_rank(gpu):
+    """bench.py --dist-at-1 under the driver's launcher (torch.distributed.run, one rank): the `nccl` process group (= RCCL) is
+    created on the box's GPU and every collective of the N > 1 path runs over it — the warm-up all-reduce, torch.distributed.reduce
+    of the f64 framebuffer after each render, the barriers, the MAX / SUM all-reduces of the timing.  The line must be a normal N = 1
+    line with the same rays as a plain run (the sum over one rank is the identity).  N > 1 itself stays unmeasured here."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-pmc", "--no-cpu-baseline", "--scene", "weekend-final", "--width", "320", "--spp-per-gpu", "8"]
+    plain = subprocess.run([sys.executable, "bench.py"] + common, cwd=root, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    for reduce in ("torch", "product"):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                            "bench.py"] + common + ["--dist-at-1", "--reduce", reduce], cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        b = json.loads(r.stdout.strip().splitlines()[-1])
+        assert b["n_gpus"] == 1 and b["rays_per_step"] == a["rays_per_step"] and b["value"] > 0, (reduce, b)
