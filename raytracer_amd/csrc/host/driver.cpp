@@ -29,7 +29,7 @@ static const char* kHelp =
     "      --spp <N>                Samples per pixel [default: 50] (addition; main.rs:75)\n"
     "      --max-depth <N>          Bounce limit [default: 50]   (addition; main.rs:76)\n"
     "      --seed <N>               Seed of the counter RNG [default: 1] (addition)\n"
-    "      --gpu-build              Build the (default, SAH position) BVH on the GPU instead of on the host (addition)\n"
+    "      --gpu-build              Build the BVH (any -o mode) or the grid on the GPU instead of on the host (addition)\n"
     "      --binary-ppm             Write the image as binary PPM (P6) instead of P3 text (addition)\n"
     "      --device <N>             GPU index [default: 0] (addition)\n"
     "      --gpus <N>               Split the samples over N GPUs, one forked worker process each, partial sums added in rank\n"
