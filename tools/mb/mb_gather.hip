@@ -3,6 +3,7 @@
 //  mode 1: cooperative: 8 lanes fetch one pair as a contiguous 128 B (8 loads per wave cover 64 pairs), staged through LDS
 //          (ds_write_b128, XOR-swizzled) and read back by the owning lane (8 x ds_read_b128)
 //  mode 2: cooperative with global_load_lds_dwordx4 (LDS-DMA, swizzle applied on the source side)
+//  mode 8 / 9: mode 3 with raw buffer loads (V# + 32-bit offsets), 64 / 32 strided live lanes
 //  mode 3: each lane loads a 64-byte pair (12 x f32 box planes + 4 x u32) with 4 x global_load_dwordx4 and widens to f64
 // The next index depends on the loaded data (dependent chain like a traversal).  Build: hipcc --offload-arch=gfx950 -O3
 #include <hip/hip_runtime.h>
@@ -26,7 +27,16 @@ __global__ __launch_bounds__(128) void k(const Pair* __restrict__ t, uint32_t n_
     char* base = lds[wv];
     for (int it = 0; it < iters; ++it) {
         double v[12]; uint32_t a, b;
-        if (MODE == 3) {
+        if (MODE == 8) {          // mode 3 through buffer loads: one V# for the table, 32-bit byte offsets per lane
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)t, 0, (int)(n_pairs * 64u), 0x00020000);
+            const uint32_t off = idx * 64u;
+            const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+            const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 0), q3 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = (double)__uint_as_float(q0[i]) * 100.0; v[4 + i] = (double)__uint_as_float(q1[i]) * 100.0; v[8 + i] = (double)__uint_as_float(q2[i]) * 100.0; }
+            a = q3[0]; b = q3[1];
+        } else if (MODE == 3) {
             const uint4* p4 = (const uint4*)((const char*)t + (size_t)idx * 64);
             const uint4 q0 = p4[0], q1 = p4[1], q2 = p4[2], q3 = p4[3];
             const float* f = (const float*)&q0; const float* g = (const float*)&q1; const float* h = (const float*)&q2;
@@ -86,7 +96,7 @@ int main(int argc, char** argv) {
         CHECK(hipMemcpy(d, h.data(), n_pairs * sizeof(Pair), hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         // 64-byte records: reuse the buffer, a/b fields of record i live at byte 64*i+48
-        for (int mode = 0; mode < 8; ++mode) for (int bl : {2048, 1024}) {
+        for (int mode = 0; mode < 10; ++mode) for (int bl : {2048, 1024}) {
             if (mode == 3 && bl == 2048) {
                 std::vector<uint32_t> h64((size_t)n_pairs * 16);
                 uint32_t s2 = 777;
@@ -104,11 +114,13 @@ int main(int argc, char** argv) {
                 if (mode == 4) hipLaunchKernelGGL((k<3, 32, false>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 if (mode == 5) hipLaunchKernelGGL((k<3, 32, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 if (mode == 6) hipLaunchKernelGGL((k<3, 16, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
+                if (mode == 9) hipLaunchKernelGGL((k<8, 32, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 if (mode == 7) hipLaunchKernelGGL((k<0, 32, true>), dim3(bl), dim3(128), 0, 0, d, n_pairs, iters, out);
                 CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
             }
-            const double frac = mode == 4 || mode == 5 || mode == 7 ? 0.5 : (mode == 6 ? 0.25 : 1.0);
+            const double frac = mode == 4 || mode == 5 || mode == 7 || mode == 9 ? 0.5 : (mode == 6 ? 0.25 : 1.0);
             double visits = (double)bl * 128 * iters * frac;
             printf("table %7.1f MB mode %d blocks %4d: %8.3f ms  %7.2f Gvisits/s  %6.2f Gcalls/s\n", n_pairs * (mode >= 3 && mode != 7 ? 64e-6 : 128e-6), mode, bl, best, visits / best / 1e6, (double)bl * 2 * iters / best / 1e6);
         }
