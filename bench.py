@@ -250,7 +250,11 @@ PMC_PASSES = {
     "sq": "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
+    # the vector-memory address path (texture addresser + vector L1) of the CUs: what the extend kernel's four divergent 16-byte lane
+    # accesses per visit load (profiles/round3_default_ta_tcp.md).  Optional: a failure of this pass leaves the rest standing
+    "ta": "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum",
 }
+PMC_OPTIONAL = {"ta"}
 
 
 def fetch_calibration():
@@ -290,6 +294,8 @@ def pmc_passes(a):
                 log, _ = p.communicate(timeout=120)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL); p.wait()
+                if name in PMC_OPTIONAL:
+                    res["optional_error"] = f"pass {name}: timed out"; continue
                 res["error"] = f"pass {name}: timed out"; break
         except OSError as e:
             res["error"] = f"pass {name}: {e}"; break
@@ -297,6 +303,8 @@ def pmc_passes(a):
         lines = [l for l in log.splitlines() if l.startswith('{"metric"')]
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if p.returncode != 0 or not lines or not f:
+            if name in PMC_OPTIONAL:
+                res["optional_error"] = f"pass {name}: rc {p.returncode}; " + log[-300:].replace("\n", " | "); continue
             res["error"] = f"pass {name}: rc {p.returncode}; " + log[-300:].replace("\n", " | "); break
         if res["child"] is None:
             res["child"] = json.loads(lines[-1])["pmc_child"]
@@ -399,6 +407,14 @@ def roofline(c, pmc):
                         "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted as fetches), so an upper bound of the HBM traffic"}
         else:
             r["traffic"] = None
+        if k.get("TA_TA_BUSY_sum") and k.get("GRBM_GUI_ACTIVE"):
+            cu_cycles = 256.0 * k["GRBM_GUI_ACTIVE"] / 8.0           # GRBM_GUI_ACTIVE is summed over the 8 XCDs; one TA / TCP per CU
+            r["ta"] = {"busy_frac": k["TA_TA_BUSY_sum"] / cu_cycles,
+                       "busy_cycles_per_wave_instruction": k["TA_TA_BUSY_sum"] / k["TA_TOTAL_WAVEFRONTS_sum"] if k.get("TA_TOTAL_WAVEFRONTS_sum") else None,
+                       "tcp_cache_accesses_per_clk_per_cu": k.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / cu_cycles,
+                       "tcp_pending_stall_frac": k.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / cu_cycles,
+                       "l1_hit_rate": 1.0 - k["TCP_TCC_READ_REQ_sum"] / k["TCP_TOTAL_CACHE_ACCESSES_sum"] if k.get("TCP_TOTAL_CACHE_ACCESSES_sum") and k.get("TCP_TCC_READ_REQ_sum") is not None else None,
+                       "note": "hardware-counter counterpart of l1_lane_access_bound: the fraction of cycles the CUs' texture addressers are busy with this kernel's loads"}
         r["pmc"] = {"source": pmc["source"], "dispatches_profiled": pmc["dispatches"], "pass_seconds": pmc["seconds"],
                     "counters": {n: v for n, v in sorted(k.items())}, "segments_profiled": ch["segments"]}
     else:
