@@ -75,6 +75,9 @@ int g_shade_mode = 3;                 // RT_SHADE_MODE bit 0: prefetch the next 
 int g_lds_tree = 1;                   // RT_LDS_TREE=0: never stage a small scene's pair / primitive tables in LDS (k_extend_bvh2<..., LDS>), 2: also for short queues, 3: fail if the scene does not qualify (tests)
 uint32_t g_lds_min_rays = 1u << 16;   // RT_LDS_MIN: queues shorter than this keep the 128-thread kernel (a short queue wants its rays spread over the CUs)
 uint32_t g_lds_bytes = 0, g_cus = 256;   // per-block LDS limit and CU count of the current device
+bool g_pair_lines = true;             // RT_PAIR_LINES=0: the lattice pair table keeps the reference's numbering (parent pair p -> left child's pair p + 1) instead of
+                                      // the line-paired order of pair_line_order() (A/B: extend 569 -> 550 ms on the headline workload)
+uint32_t g_pair_lines_min = 32768;    // RT_PAIR_LINES_MIN: ... for trees of at least this many pairs (2 MB of records)
 bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
                                       // measured 8.5 % slower on the headline workload (profiles/round3_extend_variants.md), kept for the A/B
 
@@ -151,6 +154,41 @@ struct rt_scene {
 };
 
 namespace {
+
+// Order of the 64-byte sibling-pair records in the lattice table (DPair32 / DPairN).  The traversal reads a pair right after its
+// parent's pair, and the vector L1's line is 128 bytes = two records: a pair that starts a line (even slot) is followed in the SAME line
+// by the pair of its bigger child (by box area: the child more rays enter, and enter first), so that descent finds its record in
+// the line the previous visit fetched; a pair in the second half of a line sends both children to lines of their own.  Subtrees
+// stay contiguous (depth-first, big child first).  Slots left empty by the alignment are filled with pairs that have no internal
+// child (they need no line-mate) when one is at hand, else stay zero.  Device-side numbering only: the tree, the visit order and
+// every counter are what they were.  perm[old pair] = slot; returns the number of slots (lines == false: the identity).  Pair 0 (dummy + root) and pair 1 (the
+// root's children, where every ray starts: k_extend_bvh2 derives it from the root node) keep their places.
+uint32_t pair_line_order(const std::vector<DNode>& dn, uint32_t n_nodes, size_t n_pairs, bool lines, std::vector<uint32_t>& perm) {
+    perm.assign(n_pairs, 0xffffffffu);
+    perm[0] = 0;
+    if (!lines || n_pairs < 2 || n_nodes < 3 || (dn[1].b & RT_LEAF)) { for (size_t p = 1; p < n_pairs; ++p) perm[p] = (uint32_t)p; return (uint32_t)n_pairs; }
+    auto area = [&](const DNode& X) { const double ex = X.mx[0] - X.mn[0], ey = X.mx[1] - X.mn[1], ez = X.mx[2] - X.mn[2]; return ex * ey + ey * ez + ez * ex; };
+    auto internal = [&](uint32_t di) { return !(dn[di].b & RT_LEAF); };
+    struct It { uint32_t p; bool fresh; };                 // old pair index (children of device node 2p, 2p+1 are dn[2p].a ...); must it start a line?
+    std::vector<It> todo; todo.push_back({1u, false});
+    uint32_t next = 1;
+    while (!todo.empty()) {
+        const It it = todo.back(); todo.pop_back();
+        const uint32_t l = 2 * it.p, r = l + 1;            // the two device nodes this pair describes
+        const bool li = internal(l), ri = r <= n_nodes && internal(r);
+        if (it.fresh && (next & 1u) && (li || ri)) ++next;               // a pair without internal children may sit in the second half of any line
+        const uint32_t slot = next++;
+        perm[it.p] = slot;
+        const bool mate = (slot & 1u) == 0;
+        if (li && ri) {
+            const bool left_big = area(dn[l]) >= area(dn[r]);
+            const uint32_t big = (left_big ? dn[l].a : dn[r].a) >> 1, small = (left_big ? dn[r].a : dn[l].a) >> 1;
+            todo.push_back({small, true}); todo.push_back({big, !mate});
+        } else if (li) todo.push_back({dn[l].a >> 1, !mate});
+        else if (ri) todo.push_back({dn[r].a >> 1, !mate});
+    }
+    return next;
+}
 
 // c == (f64)f32 * S bit for bit?  (then the device can rebuild c from the f32 with the same two operations)
 bool on_lattice(double c, double S, float& f) {
@@ -472,6 +510,8 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
+    g_pair_lines = true; if (const char* s = getenv("RT_PAIR_LINES")) g_pair_lines = atoi(s) != 0;
+    g_pair_lines_min = 32768; if (const char* s = getenv("RT_PAIR_LINES_MIN")) g_pair_lines_min = (uint32_t)strtoul(s, nullptr, 10);
     g_lds_tree = 1; if (const char* s = getenv("RT_LDS_TREE")) g_lds_tree = atoi(s);
     g_lds_min_rays = 1u << 16; if (const char* s = getenv("RT_LDS_MIN")) g_lds_min_rays = (uint32_t)strtoul(s, nullptr, 10);
     { int v = 0; HIPCHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device)); g_lds_bytes = v > 0 ? (uint32_t)v : 0;
@@ -682,18 +722,24 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
     // compact forms: all triangles, and every box plane and vertex coordinate on one f32 lattice (scale 100 = PLY, or 1)
     for (double S : {100.0, 1.0}) {
         bool ok = n > 0 && !empty_leaf;
-        std::vector<DPair32> pairs(((size_t)n_nodes + 2) / 2);
+        const size_t n_old_pairs = ((size_t)n_nodes + 2) / 2;
+        std::vector<uint32_t> perm;                                          // old pair index (device node >> 1) -> slot in the table
+        // (tables that fit an XCD's 4 MB L2 several times over gain nothing from it and would only grow by the alignment holes: res4, 710 KB: 35.4 vs 35.1 ms)
+        const uint32_t n_slots = pair_line_order(dn, n_nodes, n_old_pairs, g_pair_lines && n_old_pairs >= g_pair_lines_min, perm);
+        std::vector<DPair32> pairs(n_slots);
         std::vector<DPrim32> tris(n);
         for (auto& pr : pairs) memset(&pr, 0, sizeof pr);
-        for (size_t p = 0; ok && p < pairs.size(); ++p) {
+        for (size_t p = 0; ok && p < n_old_pairs; ++p) {
+            if (perm[p] == 0xffffffffu) continue;                            // not reachable from the root (cannot happen for a tree)
+            DPair32& rec = pairs[perm[p]];
             for (int side = 0; ok && side < 2; ++side) {
                 const size_t di = 2 * p + side;
                 if (di == 0 || di > n_nodes) continue;
                 const DNode& nd = dn[di];
-                float* box = pairs[p].box + 6 * side;
+                float* box = rec.box + 6 * side;
                 for (int c = 0; ok && c < 3; ++c) ok = on_lattice(nd.mn[c], S, box[c]) && on_lattice(nd.mx[c], S, box[3 + c]);
-                const uint32_t a = (nd.b & RT_LEAF) ? nd.a : nd.a >> 1;      // internal child: index of ITS children's pair
-                if (side == 0) { pairs[p].la = a; pairs[p].lb = nd.b; } else { pairs[p].ra = a; pairs[p].rb = nd.b; }
+                const uint32_t a = (nd.b & RT_LEAF) ? nd.a : perm[nd.a >> 1];   // internal child: slot of ITS children's pair
+                if (side == 0) { rec.la = a; rec.lb = nd.b; } else { rec.ra = a; rec.rb = nd.b; }
             }
         }
         for (uint32_t k = 0; ok && k < n; ++k) {
@@ -723,7 +769,7 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
             for (size_t di = 1; okn && di <= n_nodes; ++di) {
                 const DNode& X = dn[di];
                 if (X.b & RT_LEAF) continue;
-                const size_t p = X.a >> 1;                              // X's children are device nodes X.a, X.a + 1 = pair p
+                const size_t p = perm[X.a >> 1];                        // X's children are device nodes X.a, X.a + 1: their pair's slot
                 const DPair32& q = pairs[p]; DPairN& r = pn[p];
                 float own[6]; bool lat = true;
                 for (int c = 0; c < 3; ++c) lat = lat && on_lattice(X.mn[c], S, own[c]) && on_lattice(X.mx[c], S, own[3 + c]);
