@@ -160,7 +160,7 @@ namespace {
 // by the pair of its bigger child (by box area: the child more rays enter, and enter first), so that descent finds its record in
 // the line the previous visit fetched; a pair in the second half of a line sends both children to lines of their own.  Subtrees
 // stay contiguous (depth-first, big child first).  Slots left empty by the alignment are filled with pairs that have no internal
-// child (they need no line-mate) when one is at hand, else stay zero.  Device-side numbering only: the tree, the visit order and
+// child (they need no line-mate; measured: no effect on speed, the table is 22 % smaller), else stay zero.  Device-side numbering only: the tree, the visit order and
 // every counter are what they were.  perm[old pair] = slot; returns the number of slots (lines == false: the identity).  Pair 0 (dummy + root) and pair 1 (the
 // root's children, where every ray starts: k_extend_bvh2 derives it from the root node) keep their places.
 uint32_t pair_line_order(const std::vector<DNode>& dn, uint32_t n_nodes, size_t n_pairs, bool lines, std::vector<uint32_t>& perm) {
@@ -172,16 +172,19 @@ uint32_t pair_line_order(const std::vector<DNode>& dn, uint32_t n_nodes, size_t 
     struct It { uint32_t p; bool fresh; };                 // old pair index (children of device node 2p, 2p+1 are dn[2p].a ...); must it start a line?
     std::vector<It> todo; todo.push_back({1u, false});
     uint32_t next = 1;
+    std::vector<uint32_t> holes;
     while (!todo.empty()) {
         const It it = todo.back(); todo.pop_back();
         const uint32_t l = 2 * it.p, r = l + 1;            // the two device nodes this pair describes
         const bool li = internal(l), ri = r <= n_nodes && internal(r);
-        if (it.fresh && (next & 1u) && (li || ri)) ++next;               // a pair without internal children may sit in the second half of any line
-        const uint32_t slot = next++;
+        uint32_t slot;
+        if (it.fresh && (next & 1u) && (li || ri)) holes.push_back(next++);                 // start a line; the skipped slot is filled later
+        if (it.fresh && !(li || ri) && !holes.empty()) { slot = holes.back(); holes.pop_back(); }   // no internal child: needs no line-mate, any free half line does
+        else slot = next++;
         perm[it.p] = slot;
         const bool mate = (slot & 1u) == 0;
         if (li && ri) {
-            const bool left_big = area(dn[l]) >= area(dn[r]);
+            const bool left_big = area(dn[l]) >= area(dn[r]);        // measured: bigger 540.4 ms, left 545.0, right 543.9, smaller 547.7
             const uint32_t big = (left_big ? dn[l].a : dn[r].a) >> 1, small = (left_big ? dn[r].a : dn[l].a) >> 1;
             todo.push_back({small, true}); todo.push_back({big, !mate});
         } else if (li) todo.push_back({dn[l].a >> 1, !mate});
@@ -636,7 +639,7 @@ int rt_scene_bvh_layout(const rt_scene* sc, uint32_t* pair_bytes, uint32_t* prim
     const bool c32 = persistent && g_compact && sc->lattice_scale > 0.0, sph = persistent && g_compact && sc->d_spheres != nullptr;
     const bool cn = c32 && g_pairn && sc->d_pairsn != nullptr;      // 32 of the record's 64 bytes per visit (the other 32 only when a continuation enters an internal node)
     if (pair_bytes) *pair_bytes = cn ? 32u : c32 ? (uint32_t)sizeof(DPair32) : (persistent ? (uint32_t)sizeof(DPair64) : 2u * (uint32_t)sizeof(DNode));
-    if (prim_bytes) *prim_bytes = c32 ? (uint32_t)sizeof(DPrim32) : (sph ? (uint32_t)sizeof(DSphere) : (uint32_t)sizeof(DPrim));
+    if (prim_bytes) *prim_bytes = c32 ? RT_PRIM32_READ_BYTES /* bytes read per test; the table's stride is 64 */ : (sph ? (uint32_t)sizeof(DSphere) : (uint32_t)sizeof(DPrim));
     return RT_OK;
 }
 

@@ -184,11 +184,10 @@ struct __align__(16) DNode { double mn[3]; double mx[3]; uint32_t a, b, pad0, pa
 struct __align__(16) DPair64 { double box[12]; uint32_t la, lb, ra, rb; };     // box: L.mn, L.mx, R.mn, R.mx
 struct __align__(16) DSphere { double c[3]; double r; uint32_t tm, orig, pad0, pad1; };
 struct __align__(16) DPair32 { float box[12]; uint32_t la, lb, ra, rb; };      // box: L.mn, L.mx, R.mn, R.mx
-#ifdef RT_TRI64
-struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; uint32_t pad2[4]; };   // experiment: 64-byte stride, a record never straddles a 128-byte line
-#else
-struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; };          // triangles only
-#endif
+// 64-byte stride (48 bytes read): two records per 128-byte line, none straddling a line boundary (at 48-byte stride a quarter of them
+// did; extend 549.7 -> 540.9 ms on the headline workload)
+struct __align__(16) DPrim32 { float v[9]; uint32_t tm, orig, pad; uint32_t unused[4]; };   // triangles only
+#define RT_PRIM32_READ_BYTES 48u
 // DPairN: a sibling pair in TWO 16-byte accesses.  A node's box is the union of its children's boxes (objects_to_aabb folds
 // min/max, hittable_list.rs:123-133), so on each of the six faces (mn.x, mn.y, mn.z, mx.x, mx.y, mx.z) at least one child's
 // plane IS the parent's plane, bit for bit; the record keeps only the other child's plane on that face ("new" plane) and one

@@ -646,3 +646,41 @@ def test_lds_resident_tree_refuses_lattice_scenes(gpu, monkeypatch):
         monkeypatch.delenv("RT_LDS_TREE"); rt.init(0)
     assert w.hit(ro, rd)["hit"].shape == (1000,)
     w.close()
+
+
+@pytest.mark.parametrize("scene,bvh_mode", [("dragon_res4", "sah-position"), ("dragon_res4", "naive"), ("dragon_res4", "sah-plane"), ("triangle_test", "sah-position")])
+def test_line_paired_pair_table_is_bit_identical(gpu, monkeypatch, scene, bvh_mode):
+    """The lattice pair table is renumbered on the device side so that a pair's bigger child shares its 128-byte line
+    (pair_line_order, rt_api.hip; default for trees of >= 32 768 pairs — the bench mesh and dragon_res3).  RT_PAIR_LINES_MIN=0 applies it
+    to the small test meshes too: traces (counters included) and a render equal the oracle's and the reference-order table's
+    (RT_PAIR_LINES=0), also combined with the opt-in DPairN records, whose table follows the same order."""
+    import raytracer_amd as rt
+    w = load_world(scene)
+    osc = setup_pair(w, "bvh", bvh_mode, oracle_own_build=(scene != "dragon_res4" or bvh_mode != "sah-position"))
+    ro, rd = random_rays(40000, 23, -15.0, 25.0)
+    eo, ed = _edge_rays(w, 3000, 5)
+    ref = osc.trace("bvh", ro, rd, 0.001, 1e9)
+    with np.errstate(all="ignore"):
+        ref_e = osc.trace("bvh", eo, ed)
+    cam = Camera(w.filename, image_width=120, samples_per_pixel=3)
+    imgs = {}
+    for label, env in (("reference order", {"RT_PAIR_LINES": "0"}), ("line-paired", {"RT_PAIR_LINES_MIN": "0"}),
+                       ("line-paired + DPairN", {"RT_PAIR_LINES_MIN": "0", "RT_PAIRN": "1"})):
+        try:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            rt.init(0); w.upload()
+            assert_trace_equal(w.hit(ro, rd, 0.001, 1e9), ref, f"{scene}/{bvh_mode} {label}")
+            with np.errstate(all="ignore"):
+                assert_trace_equal(w.hit(eo, ed), ref_e, f"{scene}/{bvh_mode} {label} degenerate")
+            imgs[label] = cam.render(w, seed=8)
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+            rt.init(0)
+    base_img, base_st = imgs["reference order"]
+    for label, (img, st) in imgs.items():
+        assert np.array_equal(bits(img), bits(base_img)), label
+        for k in ("scatter_rays", "intersection_checks", "traversal_steps", "overlapping_aabb", "ray_segments"):
+            assert st[k] == base_st[k], (label, k)
+    w.close()
