@@ -141,6 +141,7 @@ struct rt_scene {
     uint32_t stack_blocks = 0;         // extend blocks d_stack was sized for (RT_EXTEND_BLOCKS may change between rt_init calls)
     DPair32* d_pairs32 = nullptr; DPrim32* d_prims32 = nullptr; double lattice_scale = 0.0;   // compact forms; scale 0 = not available
     DPair64* d_pairs64 = nullptr; DSphere* d_spheres = nullptr;                               // generic pairs; spheres only for all-sphere scenes
+    uint32_t pair64_stride = (uint32_t)sizeof(DPair64);                                       // 112, or 128 for big trees (one record per L1 line)
     uint32_t n_pairs64 = 0, n_bvh_prims = 0;                                                  // entries of d_pairs64 / d_prims_bvh (the LDS variant stages both)
     DPairN* d_pairsn = nullptr; uint32_t root_own[6] = {0, 0, 0, 0, 0, 0};                    // new-planes-only pairs (two accesses per visit), when the tree allows
     double root_mn[3] = {0, 0, 0}, root_mx[3] = {0, 0, 0};
@@ -249,7 +250,7 @@ int launch_extend(rt_scene* sc, int algorithm, const RayQ& in, const uint32_t* c
             hipLaunchKernelGGL(k_extend_bvh<false>, grid, block, 0, st, sc->d_nodes, sc->d_prims_bvh, in, count, n_fixed, tmin, tmax, out, sc->d_stack, d_stats);
         else {
             BvhView v; v.nodes = sc->d_nodes; v.prims = sc->d_prims_bvh; v.pairs64 = sc->d_pairs64; v.spheres = sc->d_spheres;
-            v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale;
+            v.pairs32 = sc->d_pairs32; v.prims32 = sc->d_prims32; v.scale = sc->lattice_scale; v.pair64_stride = sc->pair64_stride;
             v.pairsn = sc->d_pairsn; for (int f = 0; f < 6; ++f) v.root_own[f] = sc->root_own[f];
             const bool c32 = g_compact && sc->lattice_scale > 0.0, sph = g_compact && sc->d_spheres != nullptr;
             const bool cn = c32 && g_pairn && sc->d_pairsn != nullptr;
@@ -706,8 +707,16 @@ int rt_scene_set_bvh(rt_scene* sc, const rt_bvh_node* nodes, uint32_t n_nodes, c
                 const uint32_t a = (nd.b & RT_LEAF) ? nd.a : nd.a >> 1;
                 if (side == 0) { pairs[p].la = a; pairs[p].lb = nd.b; } else { pairs[p].ra = a; pairs[p].rb = nd.b; }
             }
-        HIPCHECK(hipMalloc(&sc->d_pairs64, pairs.size() * sizeof(DPair64)));
-        HIPCHECK(hipMemcpy(sc->d_pairs64, pairs.data(), pairs.size() * sizeof(DPair64), hipMemcpyHostToDevice));
+        // Big trees: a 128-byte stride puts every record in ONE line of the vector L1 (packed, seven of eight straddle two): the dragon
+        // mesh with RT_COMPACT=0 914 -> 859 ms extend.  Small trees stay packed: an L1/L2-resident tree only grows (weekend-final from HBM: 108 -> 122 ms).
+        sc->pair64_stride = (g_pair_lines && pairs.size() >= g_pair_lines_min) ? 128u : (uint32_t)sizeof(DPair64);
+        HIPCHECK(hipMalloc((void**)&sc->d_pairs64, pairs.size() * (size_t)sc->pair64_stride));
+        if (sc->pair64_stride == sizeof(DPair64)) HIPCHECK(hipMemcpy(sc->d_pairs64, pairs.data(), pairs.size() * sizeof(DPair64), hipMemcpyHostToDevice));
+        else {
+            std::vector<unsigned char> wide(pairs.size() * (size_t)sc->pair64_stride, 0);
+            for (size_t p = 0; p < pairs.size(); ++p) memcpy(&wide[p * sc->pair64_stride], &pairs[p], sizeof(DPair64));
+            HIPCHECK(hipMemcpy(sc->d_pairs64, wide.data(), wide.size(), hipMemcpyHostToDevice));
+        }
         sc->n_pairs64 = (uint32_t)pairs.size(); sc->n_bvh_prims = n;
         bool all_spheres = n > 0;
         for (uint32_t k = 0; all_spheres && k < n; ++k) all_spheres = sc->h_prims[prim_index[k]].type == RT_SPHERE;

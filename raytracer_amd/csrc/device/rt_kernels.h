@@ -55,7 +55,8 @@ __global__ void k_extend_bvh(const DNode* nodes, const DPrim* prims, RayQ in, co
 //   NODES 0 = DPair64 (f64 planes), 1 = DPair32 (lattice), 2 = DPairN (lattice, new planes only: two accesses per visit);  PRIMS 0 = DPrim (any mix), 1 = DPrim32 (lattice triangles), 2 = DSphere
 struct BvhView { const DNode* nodes; const DPrim* prims; const DPair64* pairs64; const DSphere* spheres;
                  const DPair32* pairs32; const DPrim32* prims32; double scale; const DPairN* pairsn; uint32_t root_own[6];
-                 uint32_t lds_pairs16, lds_prims16; };    // LDS variant: 16-byte words of pairs64 and of spheres / prims to stage
+                 uint32_t lds_pairs16, lds_prims16;
+                 uint32_t pair64_stride; };              // bytes between generic pair records: 112 (packed) or 128 (one record per L1 line, big trees)    // LDS variant: 16-byte words of pairs64 and of spheres / prims to stage
 template <int NODES, int PRIMS, bool TRACE, bool LDS = false>
 __global__ void k_extend_bvh2(BvhView bvh, RayQ in, const uint32_t* count, uint64_t n_fixed,
                               double tmin0, double tmax0, ExtendOut out, StackEntry* spill, uint32_t* fetch_ctr, uint32_t tune, unsigned long long* stats, unsigned long long* dbg);

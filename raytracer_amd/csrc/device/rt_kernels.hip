@@ -310,8 +310,9 @@ __global__ __launch_bounds__(LDS ? RT_LBLOCK : RT_BLOCK, RT_WAVES_PER_EU) void k
     const uint4* const s_prims = s_pairs + bvh.lds_pairs16;
     if constexpr (LDS) {
         uint4* dst = s_dyn + STK * BLOCK;
-        const uint4* src = (const uint4*)bvh.pairs64;
-        for (uint32_t i = tx; i < bvh.lds_pairs16; i += BLOCK) dst[i] = src[i];
+        const uint4* src = (const uint4*)bvh.pairs64;                       // records of pair64_stride bytes in HBM, their 7 words staged packed
+        const uint32_t sw = bvh.pair64_stride >> 4;
+        for (uint32_t i = tx; i < bvh.lds_pairs16; i += BLOCK) dst[i] = src[(i / 7u) * sw + i % 7u];
         dst += bvh.lds_pairs16;
         src = PRIMS == 2 ? (const uint4*)bvh.spheres : (const uint4*)bvh.prims;
         for (uint32_t i = tx; i < bvh.lds_prims16; i += BLOCK) dst[i] = src[i];
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(LDS ? RT_LBLOCK : RT_BLOCK, RT_WAVES_PER_EU) void k
 #endif
                 } else {                                 // 112-byte pair: seven accesses
                     const double2* pp;
-                    if constexpr (LDS) pp = (const double2*)(s_pairs + cur_a * 7u); else pp = (const double2*)(bvh.pairs64 + cur_a);
+                    if constexpr (LDS) pp = (const double2*)(s_pairs + cur_a * 7u); else pp = (const double2*)((const char*)bvh.pairs64 + (size_t)cur_a * bvh.pair64_stride);
                     const double2 b0 = pp[0], b1 = pp[1], b2 = pp[2], b3 = pp[3], b4 = pp[4], b5 = pp[5];
                     const uint4 m = *(const uint4*)(pp + 6);
                     dLmn[0] = b0.x - o.x; dLmn[1] = b0.y - o.y; dLmn[2] = b1.x - o.z;
