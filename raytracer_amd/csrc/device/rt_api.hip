@@ -78,6 +78,7 @@ uint32_t g_lds_bytes = 0, g_cus = 256;   // per-block LDS limit and CU count of 
 bool g_pair_lines = true;             // RT_PAIR_LINES=0: the lattice pair table keeps the reference's numbering (parent pair p -> left child's pair p + 1) instead of
                                       // the line-paired order of pair_line_order() (A/B: extend 569 -> 550 ms on the headline workload)
 uint32_t g_pair_lines_min = 32768;    // RT_PAIR_LINES_MIN: ... for trees of at least this many pairs (2 MB of records)
+bool g_shade_tri32 = true;            // RT_SHADE_TRI32=0
 bool g_pairn = false;                 // RT_PAIRN=1: lattice scenes use the 32-byte new-planes record (DPairN) instead of the 64-byte DPair32.  Opt-in:
                                       // measured 8.5 % slower on the headline workload (profiles/round3_extend_variants.md), kept for the A/B
 
@@ -402,7 +403,9 @@ int render_impl(rt_scene* sc, Workspace& w, uint32_t k, const rt_camera* cam, in
             begin_span(K_SHADE);
             {
                 const DSphere* sph = (algorithm == RT_ALGO_BVH && (g_shade_mode & 2)) ? sc->d_spheres : nullptr;     // BVH order, like sprims
-#define RT_LAUNCH_SHADE(M) hipLaunchKernelGGL(k_shade<M>, sgrid, block, 0, st, sprims, sph, sc->d_mats, sc->n_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr, \
+                // all-triangle lattice scenes: the BVH-ordered 64-byte-stride lattice triangles (RT_SHADE_TRI32=0: the 80-byte DPrim, A/B)
+                const DPrim32* t32 = (algorithm == RT_ALGO_BVH && (g_shade_mode & 2) && g_compact && sc->lattice_scale > 0.0 && g_shade_tri32) ? sc->d_prims32 : nullptr;
+#define RT_LAUNCH_SHADE(M) hipLaunchKernelGGL(k_shade<M>, sgrid, block, 0, st, sprims, sph, t32, sc->lattice_scale, sc->d_mats, sc->n_mats, w.q(b & 1), w.counts + b, w.hit_prim, w.hit_tp, sc->mixed ? w.hit_tn : nullptr, \
                                w.q((b + 1) & 1), w.counts + b + 1, w.rad, (uint32_t)WH, s_begin + s0, kb, b, max_depth, seed, w.stats)
                 switch (g_shade_mode & 3) { case 1: RT_LAUNCH_SHADE(1); break; case 2: RT_LAUNCH_SHADE(2); break; case 3: RT_LAUNCH_SHADE(3); break; default: RT_LAUNCH_SHADE(0); }
 #undef RT_LAUNCH_SHADE
@@ -514,6 +517,7 @@ int rt_init(int device) {
     if (const char* s = getenv("RT_EXTEND_VARIANT")) { int v = atoi(s); if (v == 1 || v == 2) g_extend_variant = v; }
     if (const char* s = getenv("RT_COMPACT")) g_compact = atoi(s) != 0;
     g_pairn = false; if (const char* s = getenv("RT_PAIRN")) g_pairn = atoi(s) != 0;
+    g_shade_tri32 = true; if (const char* s = getenv("RT_SHADE_TRI32")) g_shade_tri32 = atoi(s) != 0;
     g_pair_lines = true; if (const char* s = getenv("RT_PAIR_LINES")) g_pair_lines = atoi(s) != 0;
     g_pair_lines_min = 32768; if (const char* s = getenv("RT_PAIR_LINES_MIN")) g_pair_lines_min = (uint32_t)strtoul(s, nullptr, 10);
     g_lds_tree = 1; if (const char* s = getenv("RT_LDS_TREE")) g_lds_tree = atoi(s);

@@ -73,7 +73,7 @@ __global__ void k_cell_chunks(const uint64_t* cell_offset, const uint32_t* prim_
 __global__ void k_extend_grid_coop(DGrid g, const DPrim* prims, const DTriPre* pre, RayQ in, const uint32_t* count, uint64_t n_fixed,
                                    double tmin0, double tmax0, ExtendOut out, uint32_t* fetch_ctr, unsigned long long* stats);
 template <int MODE>
-__global__ void k_shade(const DPrim* prims, const DSphere* spheres, const DMat* mats, uint32_t n_mats, RayQ in, const uint32_t* count_in,
+__global__ void k_shade(const DPrim* prims, const DSphere* spheres, const DPrim32* tris32, double tri_scale, const DMat* mats, uint32_t n_mats, RayQ in, const uint32_t* count_in,
                         const int32_t* hit_prim_, const double* hit_tp, const double* hit_tn, RayQ out, uint32_t* count_out,
                         double* rad, uint32_t WH, uint32_t s_base, uint32_t s_count, uint32_t bounce, uint32_t max_depth, uint64_t seed,
                         unsigned long long* stats);

@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_COOP_WAVES) void k_extend_grid_coop(DG
 // Both measured in round 3 (profiles/round3_shade_variants.md).
 struct ShadeIn { V3 o, d, thr; uint32_t id; int32_t pi; double tp, tn; };
 template <int MODE>
-__global__ __launch_bounds__(RT_SBLOCK, (MODE & 1) ? RT_SHADE_WAVES_PF : RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DSphere* __restrict__ spheres, const DMat* __restrict__ mats, uint32_t n_mats,
+__global__ __launch_bounds__(RT_SBLOCK, (MODE & 1) ? RT_SHADE_WAVES_PF : RT_SHADE_WAVES) void k_shade(const DPrim* __restrict__ prims, const DSphere* __restrict__ spheres, const DPrim32* __restrict__ tris32, double tri_scale, const DMat* __restrict__ mats, uint32_t n_mats,
                                                     RayQ in, const uint32_t* __restrict__ count_in,
                                                     const int32_t* __restrict__ hit_prim_, const double* __restrict__ hit_tp, const double* __restrict__ hit_tn,
                                                     RayQ out, uint32_t* count_out,
@@ -1248,6 +1248,14 @@ __global__ __launch_bounds__(RT_SBLOCK, (MODE & 1) ? RT_SHADE_WAVES_PF : RT_SHAD
                     const double2 c0 = sp2[0], c1 = sp2[1]; const uint4 w2 = *(const uint4*)(sp2 + 2);
                     tm = w2.x;
                     outward = (p - v3(c0.x, c0.y, c1.x)) / c1.y;
+                } else if ((MODE & 2) && tris32) {                     // all-triangle lattice scene: the 48 bytes of the 64-byte-stride record (one L1 line, three accesses)
+                    const uint4* tp4 = (const uint4*)(tris32 + pi);
+                    const uint4 q0 = tp4[0], q1 = tp4[1], q2 = tp4[2];
+                    tm = q2.y;
+                    const V3 v0 = v3(lattice(q0.x, tri_scale), lattice(q0.y, tri_scale), lattice(q0.z, tri_scale));
+                    const V3 v1 = v3(lattice(q0.w, tri_scale), lattice(q1.x, tri_scale), lattice(q1.y, tri_scale));
+                    const V3 v2 = v3(lattice(q1.z, tri_scale), lattice(q1.w, tri_scale), lattice(q2.x, tri_scale));
+                    outward = cross(v1 - v0, v2 - v0);
                 } else {
                     DPrim P = prims[pi];
                     tm = P.tm;
@@ -1316,7 +1324,7 @@ __global__ __launch_bounds__(RT_SBLOCK, (MODE & 1) ? RT_SHADE_WAVES_PF : RT_SHAD
     }
     if (stats) stat_add(stats, ST_SCATTER, c_scatter);
 }
-#define RT_INST_SHADE(M) template __global__ void k_shade<M>(const DPrim*, const DSphere*, const DMat*, uint32_t, RayQ, const uint32_t*, const int32_t*, const double*, const double*, RayQ, uint32_t*, double*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, unsigned long long*);
+#define RT_INST_SHADE(M) template __global__ void k_shade<M>(const DPrim*, const DSphere*, const DPrim32*, double, const DMat*, uint32_t, RayQ, const uint32_t*, const int32_t*, const double*, const double*, RayQ, uint32_t*, double*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, unsigned long long*);
 RT_INST_SHADE(0) RT_INST_SHADE(1) RT_INST_SHADE(2) RT_INST_SHADE(3)
 
 // resolve: `pixel_color += ray_color(...)` (camera.rs:72) for the batch's samples, in sample order.  One lane per pixel
